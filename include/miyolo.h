@@ -1,0 +1,168 @@
+/*
+ * miyolo.h - C ABI of the MI355X-native YOLOv8 detect + classify inference path.
+ *
+ * The reference (kanaksharma67/manual-yolo) has no FFI of its own: its hot path is the
+ * Python call  results = model(frame)  into ultralytics' YOLO object
+ *     detect.py:541   model(frame)[0]                    (yolov8m detector)
+ *     detect.py:121   rank_model(crop)[0]                (yolov8n-cls classifier)
+ *     pipe.py:179     model.predict(source=frame, imgsz=1280, conf=0.35, verbose=False)
+ *     yolo.py:361     model(frame, conf=...)
+ * which runs LetterBox -> DetectionModel/ClassificationModel forward -> non_max_suppression
+ * -> Results on torch CPU kernels.  This library is what a replacement YOLO object binds
+ * instead of those torch kernels (manual_yolo_amd/engine.py is that binding, via ctypes;
+ * INTEGRATION.md shows the stub).  Each entry point names the reference-side step it
+ * replaces.
+ *
+ * Conventions
+ *   - plain C types only; all tensors are caller-owned DEVICE pointers (HBM), never freed
+ *     or reallocated by the library; weights must stay alive as long as the handle.
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (0 = null
+ *     stream); the library never synchronises and never allocates on the hot path: the
+ *     caller provides the workspace (size from miyolo_workspace_bytes).
+ *   - return value: 0 = OK, negative = miyolo_status; miyolo_last_error() gives the text.
+ *     Nothing throws across the ABI.
+ *   - a handle is bound to one device and is NOT re-entrant (one call in flight per
+ *     handle); no global state, so one process per GPU or one handle per thread both work.
+ *   - activations are NHWC; the input image batch is uint8 NHWC with 3 channels in the
+ *     channel order the packed stem weights expect (the Python host packs the stem for
+ *     BGR frames, as the reference passes them).
+ */
+#ifndef MIYOLO_H
+#define MIYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIYOLO_ABI_VERSION 1
+
+typedef enum {
+  MIYOLO_OK = 0,
+  MIYOLO_ERR_ARG = -1,         /* null pointer, bad size, bad enum */
+  MIYOLO_ERR_SHAPE = -2,       /* H/W not a multiple of the model stride, B < 1, ... */
+  MIYOLO_ERR_UNSUPPORTED = -3, /* op table uses something the kernels do not implement */
+  MIYOLO_ERR_WORKSPACE = -4,   /* workspace too small */
+  MIYOLO_ERR_HIP = -5,         /* a HIP call failed; text has the HIP error */
+  MIYOLO_ERR_NO_DEVICE = -6    /* no gfx950 device visible */
+} miyolo_status;
+
+typedef enum { MIYOLO_F32 = 0, MIYOLO_F16 = 1 } miyolo_dtype;
+
+typedef enum {
+  MIYOLO_OP_STEM = 0,     /* conv3x3 s2 p1 on the uint8 3-channel input, /255 folded in, +bias, SiLU */
+  MIYOLO_OP_CONV = 1,     /* conv kxk (k=1|3, s=1|2, p=k/2) +bias, optional SiLU, optional residual add */
+  MIYOLO_OP_MAXPOOL5 = 2, /* max_pool2d(k=5, s=1, p=2) on a channel slice (SPPF) */
+  MIYOLO_OP_DECODE = 3,   /* Detect: DFL softmax-expectation, dist2bbox, x stride, sigmoid(cls) */
+  MIYOLO_OP_CLS_HEAD = 4  /* Classify: global avg-pool + Linear + softmax */
+} miyolo_op_kind;
+
+/* A view of `ch_cnt` channels starting at `ch_off` inside activation buffer `buf`.
+ * upsample = 1 reads pixel (h>>1, w>>1) of a buffer at half the consumer's resolution
+ * (nn.Upsample(scale_factor=2, mode='nearest') folded into the consumer). buf = -1: absent. */
+typedef struct {
+  int32_t buf, ch_off, ch_cnt, upsample;
+} miyolo_view;
+
+/* Activation buffer: per image (H/down) x (W/down) x channels, NHWC.
+ * dtype: -1 = the handle's activation dtype, MIYOLO_F32 = fp32 (head outputs). */
+typedef struct {
+  int32_t channels, down, dtype, reserved;
+} miyolo_buf;
+
+/* One step of the layer program.  Replaces one fused Conv2d+BatchNorm2d+SiLU module
+ * ([3P] ultralytics.nn.modules.conv.Conv after model.fuse()), MaxPool2d, Detect._inference
+ * or Classify tail; chunk/cat/Upsample modules are expressed through views and cost nothing. */
+typedef struct {
+  int32_t kind;          /* miyolo_op_kind */
+  int32_t ksize, stride, act;     /* CONV/STEM: kernel 1|3, stride 1|2, act 0 none / 1 SiLU */
+  int32_t cin, cout;     /* CONV/STEM: logical channel counts (cin = sum of src ch_cnt) */
+  int32_t n_src;         /* CONV: 1 or 2 (channel concat of two views, k=1 only) */
+  miyolo_view src[3];    /* CONV: src[0..n_src); DECODE: the three raw head maps (box|cls, f32) */
+  miyolo_view dst;       /* CONV/STEM/MAXPOOL5: where the result goes */
+  miyolo_view res;       /* CONV: residual added AFTER the activation (Bottleneck.add) or buf=-1 */
+  int32_t weight, bias;  /* indices into the weight pointer table (CONV/STEM/CLS_HEAD) */
+  int32_t level_stride[3]; /* DECODE: stride of each level (8,16,32) */
+  int32_t reserved[5];
+} miyolo_op;
+
+typedef struct {
+  int32_t abi_version;   /* MIYOLO_ABI_VERSION */
+  int32_t task;          /* 0 = detect, 1 = classify */
+  int32_t dtype;         /* miyolo_dtype of activations and packed conv weights */
+  int32_t nc;            /* classes */
+  int32_t reg_max;       /* Detect.reg_max (16) */
+  int32_t max_stride;    /* H and W must be multiples of this (32) */
+  int32_t n_bufs, n_ops, n_weights;
+  int32_t reserved[7];
+} miyolo_desc;
+
+typedef struct miyolo_engine* miyolo_handle;
+
+/* ABI/version probes (no GPU needed). */
+int miyolo_abi_version(void);
+/* K elements per weight row are padded to a multiple of this per source view
+ * (what miyolo's conv kernels stage per step): 16 for F32, 32 for F16. */
+int miyolo_k_align(int dtype);
+
+/* Replaces: YOLO(path) model construction + AutoBackend(fuse=True) (detect.py:20-21).
+ * `weights[i]` are device pointers; conv weights are BN-folded, laid out
+ * [cout][kh][kw][cin_pad] in `desc->dtype` (cin_pad: each source view padded to
+ * miyolo_k_align); biases fp32 [cout]; the stem weight is fp32 [cout][3][3][3] with the
+ * 1/255 input scale NOT folded (the kernel applies it); CLS_HEAD weight fp32 [nc][c]. */
+int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_op* ops,
+                  const void* const* weights, int device, miyolo_handle* out);
+void miyolo_destroy(miyolo_handle h);
+const char* miyolo_last_error(miyolo_handle h); /* h may be NULL: last create() error */
+
+/* Bytes of scratch the caller must pass for a batch of B images of H x W pixels. */
+size_t miyolo_workspace_bytes(miyolo_handle h, int B, int H, int W);
+
+/* Replaces: DetectionModel forward + Detect._inference + non_max_suppression + scale_boxes
+ * (everything inside `model(frame)` after LetterBox, detect.py:541).
+ *   in          uint8 [B,H,W,3] letterboxed frames
+ *   conf, iou   thresholds (reference defaults 0.25 / 0.7); agnostic: class-agnostic NMS
+ *   max_det     rows per image in the outputs (reference default 300)
+ *   scale       optional device float [B,5] = gain, pad_x, pad_y, orig_w, orig_h to undo the
+ *               letterbox as scale_boxes/clip_boxes do; NULL leaves boxes in network pixels
+ *   out_dets    float [B,max_det,6] = x1,y1,x2,y2,conf,cls in NMS keep order (zero padded)
+ *   out_counts  int32 [B] detections kept per image
+ *   out_anchor  optional int32 [B,max_det] anchor index of every kept box (parity checks) */
+int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float conf, float iou,
+                  int agnostic, int max_det, const float* scale, float* out_dets,
+                  int32_t* out_counts, int32_t* out_anchor, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* Replaces: the forward up to Detect's return value `y` ([3P] Detect._inference):
+ * y float [B, 4+nc, A] = (cx,cy,w,h in network pixels, sigmoid class scores). The parity
+ * gate on head values (1e-4 vs the CPU path) reads this. */
+int miyolo_head_raw(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* y,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: non_max_suppression + scale_boxes alone, on a caller-supplied y [B,4+nc,A]
+ * (used to test the post-process bit-for-bit against the oracle on identical inputs). */
+int miyolo_nms(miyolo_handle h, const float* y, int B, int A, int H, int W, float conf, float iou,
+               int agnostic, int max_det, const float* scale, float* out_dets, int32_t* out_counts,
+               int32_t* out_anchor, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: ClassificationModel forward (detect.py:121, `rank_model(crop)` after the
+ * classify transforms).  in uint8 [B,H,W,3]; logits/probs float [B,nc] (either may be NULL). */
+int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* logits,
+                    float* probs, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug/parity: copy activation buffer `buf` of the last call out as fp32 NHWC
+ * [B, H/down, W/down, channels] (async on `stream`). */
+int miyolo_read_buffer(miyolo_handle h, int buf, int B, int H, int W, float* out, void* workspace,
+                       void* stream);
+
+/* Bench support: algorithmic work of one forward for a B x H x W batch, from the op table:
+ * flops = 2*MAC of the conv ops; bytes = compulsory layer-wise traffic (each op reads its
+ * inputs once, writes its output once, weights once per batch). */
+int miyolo_work(miyolo_handle h, int B, int H, int W, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIYOLO_H */
