@@ -103,15 +103,17 @@ typedef struct miyolo_engine* miyolo_handle;
 
 /* ABI/version probes (no GPU needed). */
 int miyolo_abi_version(void);
-/* K elements per weight row are padded to a multiple of this per source view
- * (what miyolo's conv kernels stage per step): 16 for F32, 32 for F16. */
+/* Conv weight rows are [cout][kpad]: K = (ky,kx,cin) flattened (concat segments in order),
+ * zero padded at the END to a multiple of this many elements (one staging step of the conv
+ * kernel, 128 B): 32 for F32, 64 for F16.  Every source view must hold a multiple of
+ * 16 B worth of channels (4 for F32, 8 for F16). */
 int miyolo_k_align(int dtype);
 
 /* Replaces: YOLO(path) model construction + AutoBackend(fuse=True) (detect.py:20-21).
- * `weights[i]` are device pointers; conv weights are BN-folded, laid out
- * [cout][kh][kw][cin_pad] in `desc->dtype` (cin_pad: each source view padded to
- * miyolo_k_align); biases fp32 [cout]; the stem weight is fp32 [cout][3][3][3] with the
- * 1/255 input scale NOT folded (the kernel applies it); CLS_HEAD weight fp32 [nc][c]. */
+ * `weights[i]` are device pointers; conv weights are BN-folded, laid out [cout][kpad]
+ * (see miyolo_k_align) in `desc->dtype`; biases fp32 [cout]; the stem weight is fp32
+ * [ky][kx][c][cout] with the 1/255 input scale NOT folded (the kernel divides the uint8
+ * pixel by 255 as the reference's preprocess does); CLS_HEAD weight fp32 [nc][c]. */
 int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_op* ops,
                   const void* const* weights, int device, miyolo_handle* out);
 void miyolo_destroy(miyolo_handle h);
@@ -152,10 +154,33 @@ int miyolo_nms(miyolo_handle h, const float* y, int B, int A, int H, int W, floa
 int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* logits,
                     float* probs, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Debug/parity: copy activation buffer `buf` of the last call out as fp32 NHWC
- * [B, H/down, W/down, channels] (async on `stream`). */
+/* Images processed per pass for a B x H x W call (the batch is split so that 32-bit element
+ * offsets suffice and, optionally, so that activations stay cache resident). */
+int miyolo_chunk(miyolo_handle h, int B, int H, int W);
+
+/* Options: "max_chunk" (images per pass, 0 = automatic), "force_wc"/"force_tc" (pin the conv
+ * tile shape: waves along channels 1|2, 16-channel tiles per wave 1..4; tests and tuning),
+ * "profile" (see miyolo_profile_read). */
+int miyolo_set_option(miyolo_handle h, const char* key, int value);
+
+/* Debug/parity taps (B must not exceed miyolo_chunk): copy activation buffer `buf` out as /
+ * in from fp32 NHWC [B, H/down, W/down, channels], and run ops [first,last) of the program.
+ * Per-layer parity tests against the oracle are built from these. */
 int miyolo_read_buffer(miyolo_handle h, int buf, int B, int H, int W, float* out, void* workspace,
                        void* stream);
+int miyolo_write_buffer(miyolo_handle h, int buf, int B, int H, int W, const float* in,
+                        void* workspace, void* stream);
+int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int B, int H, int W,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Bench support: with option "profile" = 1 every op launch is bracketed by hipEvents on the
+ * call's stream; miyolo_profile_read synchronises on them and returns, per recorded launch,
+ * the op index, the conv kernel variant (ksize*100 + waves_along_channels*10 + tiles, 0 for
+ * non-conv ops) and the duration in ms.  Returns the number of records; passing NULL arrays
+ * only counts, passing arrays consumes the records.  Not for the hot path. */
+int miyolo_profile_read(miyolo_handle h, int max_records, int32_t* op_index, int32_t* cfg, float* ms);
+/* Algorithmic flops (2*MAC) and compulsory bytes of ONE op for a B x H x W batch. */
+int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* flops, double* bytes);
 
 /* Bench support: algorithmic work of one forward for a B x H x W batch, from the op table:
  * flops = 2*MAC of the conv ops; bytes = compulsory layer-wise traffic (each op reads its

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build libmiyolo.so for gfx950 (hipcc cross-compiles without a GPU).
+#   -ffp-contract=off : the NMS box arithmetic must round exactly like the CPU reference
+#                       (no FMA contraction); FMAs that are wanted are written as fmaf().
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
+  -o libmiyolo.so miyolo.hip "$@"
+echo "built $(pwd)/libmiyolo.so"

@@ -1,0 +1,253 @@
+// Non-GEMM kernels of the YOLOv8 path: stem conv on uint8 frames, SPPF max-pool,
+// Detect decode, Classify tail.  All HBM/latency bound: coalesced NHWC access, no MFMA.
+#pragma once
+#include "common.h"
+
+namespace miyolo {
+
+// ------------------------------------------------------------------------------------
+// Stem: conv3x3 s2 p1 over the uint8 frame with the `/255` of the reference's preprocess
+// ([3P] DetectionPredictor.preprocess: im.float(); im /= 255) folded in, + bias + SiLU.
+// K = 27 is too thin for the matrix cores to matter: the layer is bound by writing
+// 2*cout bytes per output pixel, so each thread produces one output pixel for all output
+// channels, 16 at a time, with wave-uniform weights (scalar loads -> SGPR operands).
+// Weight layout: fp32 [27 = ky,kx,c][cout].
+struct StemArgs {
+  const uint8_t* in;   // [B,H,W,3]
+  const float* w;      // [27][cout]
+  const float* bias;   // [cout]
+  void* out;           // [B,H/2,W/2,cout] T
+  int32_t B, H, W, Ho, Wo, cout, act, exact;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+  const long total = (long)a.B * a.Ho * a.Wo;
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= total) return;
+  const int wo = (int)(m % a.Wo);
+  const long t = m / a.Wo;
+  const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
+  float x[27];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int hi = 2 * ho - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int wi = 2 * wo - 1 + kx;
+      const bool v = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const uint8_t* p = a.in + (((long)b * a.H + (v ? hi : 0)) * a.W + (v ? wi : 0)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = v ? (float)p[c] / 255.0f : 0.0f;
+    }
+  }
+  T* op = reinterpret_cast<T*>(a.out) + m * a.cout;
+  for (int cg = 0; cg < a.cout; cg += 16) {
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float* wk = a.w + k * a.cout + cg;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(x[k], wk[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v = acc[j] + a.bias[cg + j];
+      if (a.act) v = a.exact ? silu_exact(v) : silu_f(v);
+      acc[j] = v;
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int j = 0; j < 16; j += 4)
+        *reinterpret_cast<float4*>(op + cg + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; j += 8) {
+        f16x8 hv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[q] = (half_t)acc[j + q];
+        *reinterpret_cast<f16x8*>(op + cg + j) = hv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// MaxPool2d(k=5, s=1, p=2) on a channel slice ([3P] SPPF.m). One thread = one pixel x one
+// 16-byte channel chunk; max is exact, so any evaluation order matches the reference.
+struct PoolArgs {
+  const void* src; void* dst;
+  int32_t src_ld, src_choff, dst_ld, dst_choff, ch, B, H, W;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool5_kernel(const PoolArgs a) {
+  constexpr int CE = DT<T>::CE;
+  typedef T vec_t __attribute__((ext_vector_type(CE)));
+  const int nch = a.ch / CE;
+  const long total = (long)a.B * a.H * a.W * nch;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cc = (int)(idx % nch);
+  long p = idx / nch;
+  const int w = (int)(p % a.W);
+  p /= a.W;
+  const int h = (int)(p % a.H), b = (int)(p / a.H);
+  const T* sp = reinterpret_cast<const T*>(a.src);
+  vec_t best = *reinterpret_cast<const vec_t*>(sp + (((long)b * a.H + h) * a.W + w) * a.src_ld + a.src_choff + cc * CE);
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int hh = h + dy;
+    if (hh < 0 || hh >= a.H) continue;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int ww = w + dx;
+      if (ww < 0 || ww >= a.W) continue;
+      const vec_t v = *reinterpret_cast<const vec_t*>(sp + (((long)b * a.H + hh) * a.W + ww) * a.src_ld + a.src_choff + cc * CE);
+      best = __builtin_elementwise_max(best, v);
+    }
+  }
+  T* dp = reinterpret_cast<T*>(a.dst);
+  *reinterpret_cast<vec_t*>(dp + (((long)b * a.H + h) * a.W + w) * a.dst_ld + a.dst_choff + cc * CE) = best;
+}
+
+// ------------------------------------------------------------------------------------
+// Detect decode ([3P] Detect._inference): per anchor, DFL = softmax over the 16 bins of each
+// box side followed by the expectation sum_k k*p_k, dist2bbox(xywh=True) around the cell
+// centre (+0.5), x stride, and sigmoid on the class logits.
+//   raw  : fp32 [B, hw_l, 64+nc] per level (box logits | class logits), written by the head's
+//          final 1x1 convs
+//   y    : fp32 [B, 4+nc, A]  (A = anchors of all levels, level-major like the reference's cat)
+// One block = 64 anchors: rows are pulled through LDS (stride padded to an odd number of
+// words) so both the row-wise global reads and the channel-major global writes coalesce.
+struct DecodeArgs {
+  const float* raw[3];
+  int32_t lh[3], lw[3], lstride[3], aoff[3];   // per level grid, stride, first anchor index
+  int32_t nlevel, nc, A, B;
+  float* y;
+};
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  extern __shared__ float sm[];   // [64][no+1]
+  const int no = 64 + a.nc, ldr = no + 1;
+  const int b = blockIdx.y;
+  int a0 = blockIdx.x * 64;       // first anchor of this block (blocks never straddle levels:
+  int lvl = 0;                    //  grid.x is built per level from ceil(hw/64) blocks)
+  int blk = blockIdx.x;
+  for (lvl = 0; lvl < a.nlevel; ++lvl) {
+    const int nb = (a.lh[lvl] * a.lw[lvl] + 63) / 64;
+    if (blk < nb) break;
+    blk -= nb;
+  }
+  const int hw = a.lh[lvl] * a.lw[lvl];
+  a0 = blk * 64;
+  const int na = min(64, hw - a0);
+  const float* rp = a.raw[lvl] + ((long)b * hw + a0) * no;
+  for (int i = threadIdx.x; i < na * no; i += 256) {
+    const int r = i / no, c = i - r * no;
+    sm[r * ldr + c] = rp[i];
+  }
+  __syncthreads();
+  // phase 1: thread = (anchor, side); softmax expectation over 16 bins
+  {
+    const int an = threadIdx.x >> 2, side = threadIdx.x & 3;
+    float d = 0.f;
+    if (an < na) {
+      const float* l = sm + an * ldr + side * 16;
+      float mx = l[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) mx = fmaxf(mx, l[k]);
+      float e[16], s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { e[k] = expf(l[k] - mx); s += e[k]; }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) d += (e[k] / s) * (float)k;
+    }
+    __syncthreads();
+    if (an < na) sm[an * ldr + side] = d;   // overwrite the first 4 words of the row
+  }
+  __syncthreads();
+  float* yb = a.y + (long)b * (4 + a.nc) * a.A + a.aoff[lvl] + a0;
+  const int an = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (an < na) {
+    if (grp == 0) {
+      const int idx = a0 + an;
+      const float ax = (float)(idx % a.lw[lvl]) + 0.5f, ay = (float)(idx / a.lw[lvl]) + 0.5f;
+      const float* d = sm + an * ldr;
+      const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+      const float st = (float)a.lstride[lvl];
+      yb[0L * a.A + an] = ((x1 + x2) / 2.0f) * st;
+      yb[1L * a.A + an] = ((y1 + y2) / 2.0f) * st;
+      yb[2L * a.A + an] = (x2 - x1) * st;
+      yb[3L * a.A + an] = (y2 - y1) * st;
+    }
+    for (int c = grp; c < a.nc; c += 4) {
+      const float v = sm[an * ldr + 64 + c];
+      yb[(long)(4 + c) * a.A + an] = 1.0f / (1.0f + expf(-v));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Classify tail ([3P] Classify.forward after its Conv): AdaptiveAvgPool2d(1) -> flatten ->
+// Linear(c -> nc) -> softmax.  One block per image.
+struct ClsHeadArgs {
+  const void* feat;    // [B, hw, c] T
+  const float* w;      // [nc][c]
+  const float* bias;   // [nc]
+  float* logits;       // [B, nc] or null
+  float* probs;        // [B, nc] or null
+  int32_t B, hw, c, nc;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_head_kernel(const ClsHeadArgs a) {
+  extern __shared__ float sm[];          // pooled[c] + logits[nc]
+  float* pooled = sm;
+  float* lg = sm + a.c;
+  const int b = blockIdx.x;
+  const T* f = reinterpret_cast<const T*>(a.feat) + (long)b * a.hw * a.c;
+  for (int ch = threadIdx.x; ch < a.c; ch += 256) {
+    float s = 0.f;
+    for (int p = 0; p < a.hw; ++p) s += (float)f[(long)p * a.c + ch];
+    pooled[ch] = s / (float)a.hw;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < a.nc; k += 4) {
+    const float* wr = a.w + (long)k * a.c;
+    float s = 0.f;
+    for (int ch = lane; ch < a.c; ch += 64) s = fmaf(pooled[ch], wr[ch], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) lg[k] = s + a.bias[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = lg[0];
+    for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, lg[k]);
+    float s = 0.f;
+    for (int k = 0; k < a.nc; ++k) s += expf(lg[k] - mx);
+    for (int k = 0; k < a.nc; ++k) {
+      if (a.logits) a.logits[(long)b * a.nc + k] = lg[k];
+      if (a.probs) a.probs[(long)b * a.nc + k] = expf(lg[k] - mx) / s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Debug / parity taps: fp32 <-> activation dtype copies of a whole buffer.
+template <typename T>
+__global__ void copy_to_f32_kernel(const T* src, float* dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+template <typename T>
+__global__ void copy_from_f32_kernel(const float* src, T* dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (T)src[i];
+}
+
+}  // namespace miyolo

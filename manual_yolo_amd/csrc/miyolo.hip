@@ -1,0 +1,618 @@
+// miyolo engine: executes the layer program of include/miyolo.h with the gfx950 kernels.
+// C ABI only at the boundary; no torch types, no allocation or synchronisation on the hot
+// path (the caller passes the workspace and the stream).
+#include "../../include/miyolo.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_igemm.h"
+#include "kernels_misc.h"
+#include "nms.h"
+
+using namespace miyolo;
+
+namespace {
+
+std::string g_create_error;
+
+struct Plan {
+  int B = 0, H = 0, W = 0;            // chunk batch and frame size the offsets are valid for
+  std::vector<size_t> buf_off;        // byte offset of every activation buffer
+  size_t y_off = 0, keys_off = 0, count_off = 0, cls_off = 0, total = 0;
+  int A = 0, P = 1;
+};
+
+}  // namespace
+
+struct miyolo_engine {
+  miyolo_desc desc;
+  std::vector<miyolo_buf> bufs;
+  std::vector<miyolo_op> ops;
+  std::vector<const void*> weights;
+  int device = 0;
+  int max_chunk = 0;        // 0 = automatic
+  int force_wc = 0, force_tc = 0;
+  int profile = 0;          // 1: bracket every op launch with hipEvents (bench/roofline only)
+  struct ProfRec { int op, cfg; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof;
+  std::string err;
+  Plan plan;
+};
+
+namespace {
+
+int fail(miyolo_engine* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return fail(h, MIYOLO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+inline size_t elem_size(const miyolo_engine* h, const miyolo_buf& b) {
+  if (b.dtype == -2) return 1;                       // uint8 input
+  if (b.dtype == MIYOLO_F32) return 4;
+  return h->desc.dtype == MIYOLO_F16 ? 2 : 4;        // -1: activation dtype
+}
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <typename T, int KS, int WC, int TC>
+hipError_t set_conv_attr() {
+  constexpr int BM = (4 / WC) * TP * 16, BN = WC * TC * 16;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, KS, WC, TC>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * ROW_BYTES);
+}
+template <typename T, int KS>
+hipError_t set_conv_attrs_ks() {
+  hipError_t e;
+  if ((e = set_conv_attr<T, KS, 2, 4>()) != hipSuccess) return e;
+  if ((e = set_conv_attr<T, KS, 2, 3>()) != hipSuccess) return e;
+  if ((e = set_conv_attr<T, KS, 1, 4>()) != hipSuccess) return e;
+  if ((e = set_conv_attr<T, KS, 1, 3>()) != hipSuccess) return e;
+  if ((e = set_conv_attr<T, KS, 1, 2>()) != hipSuccess) return e;
+  return set_conv_attr<T, KS, 1, 1>();
+}
+
+int nms_lds_bytes(int max_det) { return ((max_det * 5 * 4 + 15) & ~15) + kNmsLdsKeys * 8; }
+
+// Largest number of images per pass such that every buffer stays below 2 GiB (the kernels use
+// 32-bit byte offsets, and raw-buffer loads use offset 0x80000000 as the "reads zero" marker).
+int auto_chunk(const miyolo_engine* h, int B, int H, int W) {
+  size_t per_img = 1;
+  for (const miyolo_buf& b : h->bufs) {
+    const size_t e = (size_t)(H / b.down) * (W / b.down) * b.channels * elem_size(h, b);
+    if (e > per_img) per_img = e;
+  }
+  size_t lim = (((size_t)1 << 31) - 1) / per_img;
+  if (lim < 1) lim = 1;
+  int c = (int)std::min<size_t>(lim, (size_t)B);
+  if (h->max_chunk > 0 && c > h->max_chunk) c = h->max_chunk;
+  return c;
+}
+
+int total_anchors(const miyolo_engine* h, int H, int W) {
+  int A = 0;
+  for (const miyolo_op& op : h->ops)
+    if (op.kind == MIYOLO_OP_DECODE)
+      for (int l = 0; l < 3; ++l) A += (H / op.level_stride[l]) * (W / op.level_stride[l]);
+  return A;
+}
+
+void make_plan(const miyolo_engine* h, int Bc, int H, int W, Plan* p) {
+  p->B = Bc; p->H = H; p->W = W;
+  p->buf_off.assign(h->bufs.size(), 0);
+  size_t off = 0;
+  for (size_t i = 1; i < h->bufs.size(); ++i) {   // buffer 0 is the caller's input
+    const miyolo_buf& b = h->bufs[i];
+    p->buf_off[i] = off;
+    off += align_up((size_t)Bc * (H / b.down) * (W / b.down) * b.channels * elem_size(h, b), 256);
+  }
+  p->A = total_anchors(h, H, W);
+  p->P = 1;
+  while (p->P < p->A) p->P <<= 1;
+  if (h->desc.task == 0) {
+    p->y_off = off;     off += align_up((size_t)Bc * (4 + h->desc.nc) * p->A * 4, 256);
+    p->keys_off = off;  off += align_up((size_t)Bc * p->P * 8, 256);
+    p->count_off = off; off += align_up((size_t)Bc * 4, 256);
+    p->cls_off = off;   off += align_up((size_t)Bc * p->A * 4, 256);
+  }
+  p->total = off;
+}
+
+int check_shape(miyolo_engine* h, int B, int H, int W) {
+  if (B < 1 || H < 1 || W < 1) return fail(h, MIYOLO_ERR_SHAPE, "bad batch/frame size B=%d H=%d W=%d", B, H, W);
+  if (H % h->desc.max_stride || W % h->desc.max_stride)
+    return fail(h, MIYOLO_ERR_SHAPE, "H=%d W=%d must be multiples of the model stride %d", H, W, h->desc.max_stride);
+  return 0;
+}
+
+struct DevGuard {
+  int prev = -1; bool sw = false;
+  explicit DevGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) { sw = hipSetDevice(dev) == hipSuccess; } }
+  ~DevGuard() { if (sw) (void)hipSetDevice(prev); }
+};
+
+void* buf_ptr(const miyolo_engine* h, const Plan& p, int buf, const void* in, void* ws) {
+  if (buf == 0) return const_cast<void*>(in);
+  return static_cast<unsigned char*>(ws) + p.buf_off[buf];
+}
+
+template <typename T>
+int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in, void* ws,
+           float* cls_logits, float* cls_probs, hipStream_t s) {
+  const int Bc = p.B, H = p.H, W = p.W;
+  switch (op.kind) {
+    case MIYOLO_OP_STEM: {
+      const miyolo_buf& ob = h->bufs[op.dst.buf];
+      StemArgs a;
+      a.in = static_cast<const uint8_t*>(in);
+      a.w = static_cast<const float*>(h->weights[op.weight]);
+      a.bias = static_cast<const float*>(h->weights[op.bias]);
+      a.out = buf_ptr(h, p, op.dst.buf, in, ws);
+      a.B = Bc; a.H = H; a.W = W; a.Ho = H / ob.down; a.Wo = W / ob.down;
+      a.cout = op.cout; a.act = op.act; a.exact = (h->desc.dtype == MIYOLO_F32);
+      if (op.cout % 16 || op.dst.ch_off != 0 || ob.channels != op.cout || ob.down != 2)
+        return fail(h, MIYOLO_ERR_UNSUPPORTED, "stem: cout=%d must be a multiple of 16 and own its buffer", op.cout);
+      const long total = (long)Bc * a.Ho * a.Wo;
+      hipLaunchKernelGGL(stem_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+      break;
+    }
+    case MIYOLO_OP_CONV: {
+      constexpr int CE = DT<T>::CE;
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      const miyolo_buf& ob = h->bufs[op.dst.buf];
+      a.nsrc = op.n_src;
+      int down_in = 0, ktot = 0;
+      for (int i = 0; i < op.n_src; ++i) {
+        const miyolo_view& v = op.src[i];
+        const miyolo_buf& sb = h->bufs[v.buf];
+        if (v.buf == 0 || sb.dtype != -1) return fail(h, MIYOLO_ERR_UNSUPPORTED, "conv source must be an activation buffer");
+        a.src[i].ptr = buf_ptr(h, p, v.buf, in, ws);
+        a.src[i].ld = sb.channels; a.src[i].ch_off = v.ch_off; a.src[i].ch_cnt = v.ch_cnt; a.src[i].up = v.upsample;
+        a.src[i].h = H / sb.down; a.src[i].w = W / sb.down;
+        a.src[i].bytes = (uint32_t)((size_t)Bc * a.src[i].h * a.src[i].w * sb.channels * sizeof(T));
+        const int d = v.upsample ? sb.down / 2 : sb.down;
+        if (i == 0) down_in = d; else if (d != down_in) return fail(h, MIYOLO_ERR_UNSUPPORTED, "concat of different resolutions");
+        if (v.ch_cnt % CE || v.ch_off % CE || sb.channels % CE)
+          return fail(h, MIYOLO_ERR_UNSUPPORTED, "conv view channels (%d @%d of %d) must be multiples of %d", v.ch_cnt, v.ch_off, sb.channels, CE);
+        ktot += v.ch_cnt;
+      }
+      if (op.n_src == 1) a.src[1] = a.src[0];
+      if (op.n_src == 2 && op.src[0].ch_cnt % (8 * CE))
+        return fail(h, MIYOLO_ERR_UNSUPPORTED, "first concat segment (%d ch) must be a multiple of %d channels", op.src[0].ch_cnt, 8 * CE);
+      if (ktot != op.cin) return fail(h, MIYOLO_ERR_ARG, "conv cin mismatch");
+      if (op.ksize == 3 && (op.n_src != 1 || op.src[0].upsample)) return fail(h, MIYOLO_ERR_UNSUPPORTED, "3x3 conv over concat/upsample");
+      if (op.ksize == 1 && op.stride != 1) return fail(h, MIYOLO_ERR_UNSUPPORTED, "strided 1x1 conv");
+      if (op.ksize != 1 && op.ksize != 3) return fail(h, MIYOLO_ERR_UNSUPPORTED, "conv kernel size %d", op.ksize);
+      a.w = h->weights[op.weight];
+      a.bias = static_cast<const float*>(h->weights[op.bias]);
+      a.dst = buf_ptr(h, p, op.dst.buf, in, ws);
+      a.dst_ld = ob.channels; a.dst_choff = op.dst.ch_off; a.out_f32 = (ob.dtype == MIYOLO_F32);
+      if (op.res.buf >= 0) {
+        a.res = buf_ptr(h, p, op.res.buf, in, ws);
+        a.res_ld = h->bufs[op.res.buf].channels; a.res_choff = op.res.ch_off;
+      }
+      a.B = Bc; a.Hin = H / down_in; a.Win = W / down_in; a.Hout = H / ob.down; a.Wout = W / ob.down;
+      if (down_in * op.stride != ob.down) return fail(h, MIYOLO_ERR_ARG, "conv resolution mismatch");
+      a.cin = op.cin; a.cout = op.cout; a.ksize = op.ksize; a.stride = op.stride; a.act = op.act;
+      a.M = Bc * a.Hout * a.Wout;
+      const int K = op.cin * op.ksize * op.ksize, BK = 8 * CE;
+      a.kpad = (K + BK - 1) / BK * BK; a.nk = a.kpad / BK;
+      a.wbytes = (uint32_t)((size_t)op.cout * a.kpad * sizeof(T));
+      a.vec_ok = (op.cout % 4 == 0) && (ob.channels % 4 == 0) && (op.dst.ch_off % 4 == 0);
+      a.exact = (h->desc.dtype == MIYOLO_F32);
+      HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
+      break;
+    }
+    case MIYOLO_OP_MAXPOOL5: {
+      constexpr int CE = DT<T>::CE;
+      const miyolo_buf& sb = h->bufs[op.src[0].buf];
+      const miyolo_buf& ob = h->bufs[op.dst.buf];
+      PoolArgs a;
+      a.src = buf_ptr(h, p, op.src[0].buf, in, ws); a.dst = buf_ptr(h, p, op.dst.buf, in, ws);
+      a.src_ld = sb.channels; a.src_choff = op.src[0].ch_off; a.dst_ld = ob.channels; a.dst_choff = op.dst.ch_off;
+      a.ch = op.src[0].ch_cnt; a.B = Bc; a.H = H / sb.down; a.W = W / sb.down;
+      if (a.ch % CE || a.src_choff % CE || a.dst_choff % CE || a.src_ld % CE || a.dst_ld % CE)
+        return fail(h, MIYOLO_ERR_UNSUPPORTED, "maxpool channel slice must be a multiple of %d", CE);
+      const long total = (long)Bc * a.H * a.W * (a.ch / CE);
+      hipLaunchKernelGGL(maxpool5_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+      break;
+    }
+    case MIYOLO_OP_DECODE: {
+      DecodeArgs a;
+      memset(&a, 0, sizeof(a));
+      a.nlevel = 3; a.nc = h->desc.nc; a.A = p.A; a.B = Bc;
+      int aoff = 0, nblk = 0;
+      for (int l = 0; l < 3; ++l) {
+        const miyolo_buf& rb = h->bufs[op.src[l].buf];
+        if (rb.dtype != MIYOLO_F32 || rb.channels != 64 + a.nc || h->desc.reg_max != 16)
+          return fail(h, MIYOLO_ERR_UNSUPPORTED, "decode expects fp32 raw maps of 64+nc channels (reg_max 16)");
+        a.raw[l] = static_cast<const float*>(buf_ptr(h, p, op.src[l].buf, in, ws));
+        a.lh[l] = H / rb.down; a.lw[l] = W / rb.down; a.lstride[l] = op.level_stride[l]; a.aoff[l] = aoff;
+        aoff += a.lh[l] * a.lw[l];
+        nblk += (a.lh[l] * a.lw[l] + 63) / 64;
+      }
+      a.y = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + p.y_off);
+      const size_t lds = (size_t)64 * (64 + a.nc + 1) * 4;
+      hipLaunchKernelGGL(decode_kernel, dim3(nblk, Bc), dim3(256), lds, s, a);
+      break;
+    }
+    case MIYOLO_OP_CLS_HEAD: {
+      const miyolo_buf& sb = h->bufs[op.src[0].buf];
+      ClsHeadArgs a;
+      a.feat = buf_ptr(h, p, op.src[0].buf, in, ws);
+      a.w = static_cast<const float*>(h->weights[op.weight]);
+      a.bias = static_cast<const float*>(h->weights[op.bias]);
+      a.logits = cls_logits; a.probs = cls_probs;
+      a.B = Bc; a.hw = (H / sb.down) * (W / sb.down); a.c = op.cin; a.nc = op.cout;
+      if (op.src[0].ch_off != 0 || sb.channels != op.cin) return fail(h, MIYOLO_ERR_UNSUPPORTED, "cls head must read a whole buffer");
+      hipLaunchKernelGGL(cls_head_kernel<T>, dim3(Bc), dim3(256), (size_t)(a.c + a.nc) * 4, s, a);
+      break;
+    }
+    default:
+      return fail(h, MIYOLO_ERR_UNSUPPORTED, "unknown op kind %d", op.kind);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
+  if (op.kind != MIYOLO_OP_CONV) return 0;
+  const miyolo_buf& ob = h->bufs[op.dst.buf];
+  ConvCfg c = pick_conv_cfg(op.cout, (long)p.B * (p.H / ob.down) * (p.W / ob.down));
+  if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
+  return op.ksize * 100 + c.wc * 10 + c.tc;      // e.g. 324 = conv_igemm_kernel<T,3,2,4>
+}
+
+int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
+            float* cls_logits, float* cls_probs, hipStream_t s) {
+  for (int i = first; i < last; ++i) {
+    miyolo_engine::ProfRec rec{i, 0, nullptr, nullptr};
+    if (h->profile) {
+      rec.cfg = conv_cfg_id(h, h->ops[i], p);
+      HIP_TRY(h, hipEventCreate(&rec.e0));
+      HIP_TRY(h, hipEventCreate(&rec.e1));
+      HIP_TRY(h, hipEventRecord(rec.e0, s));
+    }
+    const int rc = (h->desc.dtype == MIYOLO_F16)
+                       ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s)
+                       : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s);
+    if (rc) return rc;
+    if (h->profile) {
+      HIP_TRY(h, hipEventRecord(rec.e1, s));
+      h->prof.push_back(rec);
+    }
+  }
+  return 0;
+}
+
+int run_nms(miyolo_engine* h, const Plan& p, const float* y, int Bc, int A, float conf, float iou, int agnostic,
+            int max_det, const float* scale, float* out_dets, int32_t* out_counts, int32_t* out_anchor,
+            void* ws, hipStream_t s) {
+  NmsArgs a;
+  a.y = y; a.B = Bc; a.A = A; a.nc = h->desc.nc; a.max_det = max_det; a.agnostic = agnostic; a.P = p.P;
+  a.conf = conf; a.iou = iou; a.scale = scale;
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  a.keys = reinterpret_cast<unsigned long long*>(w + p.keys_off);
+  a.count = reinterpret_cast<int32_t*>(w + p.count_off);
+  a.cls_idx = reinterpret_cast<int32_t*>(w + p.cls_off);
+  a.out_dets = out_dets; a.out_counts = out_counts; a.out_anchor = out_anchor;
+  HIP_TRY(h, hipMemsetAsync(a.count, 0, (size_t)Bc * 4, s));
+  hipLaunchKernelGGL(nms_prefilter_kernel, dim3((A + 255) / 256, Bc), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(nms_sort_greedy_kernel, dim3(Bc), dim3(kNmsThreads), (size_t)nms_lds_bytes(max_det), s, a);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int prepare(miyolo_engine* h, int B, int H, int W, size_t ws_bytes, void* ws) {
+  if (int rc = check_shape(h, B, H, W)) return rc;
+  if (!ws) return fail(h, MIYOLO_ERR_ARG, "workspace is null");
+  const int Bc = auto_chunk(h, B, H, W);
+  if (h->plan.B != Bc || h->plan.H != H || h->plan.W != W) make_plan(h, Bc, H, W, &h->plan);
+  if (ws_bytes < h->plan.total)
+    return fail(h, MIYOLO_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, h->plan.total);
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int miyolo_abi_version(void) { return MIYOLO_ABI_VERSION; }
+
+int miyolo_k_align(int dtype) { return dtype == MIYOLO_F16 ? 64 : 32; }
+
+int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_op* ops,
+                  const void* const* weights, int device, miyolo_handle* out) {
+  if (!desc || !bufs || !ops || !weights || !out) return fail(nullptr, MIYOLO_ERR_ARG, "null argument");
+  if (desc->abi_version != MIYOLO_ABI_VERSION) return fail(nullptr, MIYOLO_ERR_ARG, "ABI version %d != %d", desc->abi_version, MIYOLO_ABI_VERSION);
+  if (desc->dtype != MIYOLO_F32 && desc->dtype != MIYOLO_F16) return fail(nullptr, MIYOLO_ERR_ARG, "bad dtype %d", desc->dtype);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MIYOLO_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(nullptr, MIYOLO_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+  hipDeviceProp_t prop;
+  HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+  if (!strstr(prop.gcnArchName, "gfx950"))
+    return fail(nullptr, MIYOLO_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  DevGuard guard(device);
+  miyolo_engine* h = new miyolo_engine();
+  h->desc = *desc;
+  h->device = device;
+  h->bufs.assign(bufs, bufs + desc->n_bufs);
+  h->ops.assign(ops, ops + desc->n_ops);
+  h->weights.assign(weights, weights + desc->n_weights);
+  for (const miyolo_op& op : h->ops) {
+    const bool needs_w = op.kind == MIYOLO_OP_STEM || op.kind == MIYOLO_OP_CONV || op.kind == MIYOLO_OP_CLS_HEAD;
+    if (needs_w && (op.weight < 0 || op.weight >= desc->n_weights || op.bias < 0 || op.bias >= desc->n_weights ||
+                    !h->weights[op.weight] || !h->weights[op.bias])) {
+      delete h;
+      return fail(nullptr, MIYOLO_ERR_ARG, "op references a missing weight");
+    }
+  }
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = set_conv_attrs_ks<float, 1>();
+  if (e == hipSuccess) e = set_conv_attrs_ks<float, 3>();
+  if (e == hipSuccess) e = set_conv_attrs_ks<half_t, 1>();
+  if (e == hipSuccess) e = set_conv_attrs_ks<half_t, 3>();
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_greedy_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, nms_lds_bytes(1024));
+  if (e != hipSuccess) {
+    delete h;
+    return fail(nullptr, MIYOLO_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return 0;
+}
+
+void miyolo_destroy(miyolo_handle h) { delete h; }
+
+const char* miyolo_last_error(miyolo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int miyolo_set_option(miyolo_handle h, const char* key, int value) {
+  if (!h || !key) return MIYOLO_ERR_ARG;
+  if (!strcmp(key, "max_chunk")) { h->max_chunk = value; h->plan = Plan(); return 0; }
+  if (!strcmp(key, "force_wc")) { h->force_wc = value; return 0; }
+  if (!strcmp(key, "force_tc")) { h->force_tc = value; return 0; }
+  if (!strcmp(key, "profile")) { h->profile = value; return 0; }
+  return fail(h, MIYOLO_ERR_ARG, "unknown option %s", key);
+}
+
+size_t miyolo_workspace_bytes(miyolo_handle h, int B, int H, int W) {
+  if (!h || check_shape(h, B, H, W)) return 0;
+  Plan p;
+  make_plan(h, auto_chunk(h, B, H, W), H, W, &p);
+  return p.total;
+}
+
+int miyolo_chunk(miyolo_handle h, int B, int H, int W) {
+  if (!h || check_shape(h, B, H, W)) return 0;
+  return auto_chunk(h, B, H, W);
+}
+
+int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float conf, float iou,
+                  int agnostic, int max_det, const float* scale, float* out_dets, int32_t* out_counts,
+                  int32_t* out_anchor, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 0) return fail(h, MIYOLO_ERR_ARG, "not a detection model");
+  if (!in || !out_dets || !out_counts) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  if (max_det < 1 || max_det > 1024) return fail(h, MIYOLO_ERR_ARG, "max_det %d out of range [1,1024]", max_det);
+  if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Plan& p = h->plan;
+  const float* y = reinterpret_cast<const float*>(static_cast<unsigned char*>(workspace) + p.y_off);
+  for (int b0 = 0; b0 < B; b0 += p.B) {
+    Plan pc = p;
+    pc.B = std::min(p.B, B - b0);
+    if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s)) return rc;
+    if (int rc = run_nms(h, pc, y, pc.B, p.A, conf, iou, agnostic, max_det, scale ? scale + (size_t)b0 * 5 : nullptr,
+                         out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
+                         out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, s)) return rc;
+  }
+  return 0;
+}
+
+int miyolo_head_raw(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* y_out, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 0) return fail(h, MIYOLO_ERR_ARG, "not a detection model");
+  if (!in || !y_out) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Plan& p = h->plan;
+  const size_t per = (size_t)(4 + h->desc.nc) * p.A;
+  for (int b0 = 0; b0 < B; b0 += p.B) {
+    Plan pc = p;
+    pc.B = std::min(p.B, B - b0);
+    if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s)) return rc;
+    HIP_TRY(h, hipMemcpyAsync(y_out + (size_t)b0 * per, static_cast<unsigned char*>(workspace) + p.y_off,
+                              (size_t)pc.B * per * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+int miyolo_nms(miyolo_handle h, const float* y, int B, int A, int H, int W, float conf, float iou, int agnostic,
+               int max_det, const float* scale, float* out_dets, int32_t* out_counts, int32_t* out_anchor,
+               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 0) return fail(h, MIYOLO_ERR_ARG, "not a detection model");
+  if (!y || !out_dets || !out_counts) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  if (max_det < 1 || max_det > 1024) return fail(h, MIYOLO_ERR_ARG, "max_det %d out of range [1,1024]", max_det);
+  if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
+  if (A != h->plan.A) return fail(h, MIYOLO_ERR_SHAPE, "A=%d does not match the %d anchors of a %dx%d frame", A, h->plan.A, H, W);
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Plan& p = h->plan;
+  const size_t per = (size_t)(4 + h->desc.nc) * p.A;
+  for (int b0 = 0; b0 < B; b0 += p.B) {
+    Plan pc = p;
+    pc.B = std::min(p.B, B - b0);
+    if (int rc = run_nms(h, pc, y + (size_t)b0 * per, pc.B, A, conf, iou, agnostic, max_det,
+                         scale ? scale + (size_t)b0 * 5 : nullptr, out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
+                         out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, s)) return rc;
+  }
+  return 0;
+}
+
+int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* logits, float* probs,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 1) return fail(h, MIYOLO_ERR_ARG, "not a classification model");
+  if (!in) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Plan& p = h->plan;
+  const int nc = h->desc.nc;
+  for (int b0 = 0; b0 < B; b0 += p.B) {
+    Plan pc = p;
+    pc.B = std::min(p.B, B - b0);
+    if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace,
+                         logits ? logits + (size_t)b0 * nc : nullptr, probs ? probs + (size_t)b0 * nc : nullptr, s)) return rc;
+  }
+  return 0;
+}
+
+int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int B, int H, int W, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (first < 0 || last > (int)h->ops.size() || first > last) return fail(h, MIYOLO_ERR_ARG, "bad op range");
+  if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
+  if (h->plan.B < B) return fail(h, MIYOLO_ERR_SHAPE, "debug entry points need B <= chunk (%d)", h->plan.B);
+  DevGuard guard(h->device);
+  return run_ops(h, first, last, h->plan, in, workspace, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+static int debug_buf(miyolo_handle h, int buf, int B, int H, int W, long* n) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (buf < 1 || buf >= (int)h->bufs.size()) return fail(h, MIYOLO_ERR_ARG, "bad buffer index %d", buf);
+  if (int rc = check_shape(h, B, H, W)) return rc;
+  const int Bc = auto_chunk(h, B, H, W);
+  if (Bc < B) return fail(h, MIYOLO_ERR_SHAPE, "debug entry points need B <= chunk (%d)", Bc);
+  if (h->plan.B != Bc || h->plan.H != H || h->plan.W != W) make_plan(h, Bc, H, W, &h->plan);
+  const miyolo_buf& b = h->bufs[buf];
+  *n = (long)B * (H / b.down) * (W / b.down) * b.channels;
+  return 0;
+}
+
+int miyolo_read_buffer(miyolo_handle h, int buf, int B, int H, int W, float* out, void* workspace, void* stream) {
+  long n = 0;
+  if (int rc = debug_buf(h, buf, B, H, W, &n)) return rc;
+  if (!out || !workspace) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const void* src = static_cast<unsigned char*>(workspace) + h->plan.buf_off[buf];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (elem_size(h, h->bufs[buf]) == 4) {
+    HIP_TRY(h, hipMemcpyAsync(out, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    hipLaunchKernelGGL(copy_to_f32_kernel<half_t>, dim3(g), dim3(256), 0, s, static_cast<const half_t*>(src), out, n);
+    HIP_TRY(h, hipGetLastError());
+  }
+  return 0;
+}
+
+int miyolo_write_buffer(miyolo_handle h, int buf, int B, int H, int W, const float* in, void* workspace, void* stream) {
+  long n = 0;
+  if (int rc = debug_buf(h, buf, B, H, W, &n)) return rc;
+  if (!in || !workspace) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  void* dst = static_cast<unsigned char*>(workspace) + h->plan.buf_off[buf];
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (elem_size(h, h->bufs[buf]) == 4) {
+    HIP_TRY(h, hipMemcpyAsync(dst, in, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    hipLaunchKernelGGL(copy_from_f32_kernel<half_t>, dim3(g), dim3(256), 0, s, in, static_cast<half_t*>(dst), n);
+    HIP_TRY(h, hipGetLastError());
+  }
+  return 0;
+}
+
+int miyolo_profile_read(miyolo_handle h, int max_records, int32_t* op_index, int32_t* cfg, float* ms) {
+  if (!h) return MIYOLO_ERR_ARG;
+  DevGuard guard(h->device);
+  int n = 0;
+  for (auto& r : h->prof) {
+    if (n < max_records && op_index && cfg && ms) {
+      HIP_TRY(h, hipEventSynchronize(r.e1));
+      float t = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&t, r.e0, r.e1));
+      op_index[n] = r.op; cfg[n] = r.cfg; ms[n] = t;
+    }
+    ++n;
+  }
+  if (op_index) {       // a read with buffers consumes the records
+    for (auto& r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    h->prof.clear();
+  }
+  return n;
+}
+
+int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* flops, double* bytes) {
+  if (!h || op_index < 0 || op_index >= (int)h->ops.size()) return MIYOLO_ERR_ARG;
+  if (int rc = check_shape(h, B, H, W)) return rc;
+  const miyolo_op& op = h->ops[op_index];
+  double fl = 0, by = 0;
+  const double es = h->desc.dtype == MIYOLO_F16 ? 2 : 4;
+  if (op.kind == MIYOLO_OP_CONV || op.kind == MIYOLO_OP_STEM) {
+    const miyolo_buf& ob = h->bufs[op.dst.buf];
+    const double mo = (double)B * (H / ob.down) * (W / ob.down);
+    fl = 2.0 * mo * op.cout * op.cin * op.ksize * op.ksize;
+    if (op.kind == MIYOLO_OP_STEM) {
+      by += (double)B * H * W * 3;
+    } else {
+      for (int i = 0; i < op.n_src; ++i) {
+        const miyolo_buf& sb = h->bufs[op.src[i].buf];
+        by += (double)B * (H / sb.down) * (W / sb.down) * op.src[i].ch_cnt * es;
+      }
+    }
+    by += mo * op.cout * (ob.dtype == MIYOLO_F32 ? 4 : es);
+    by += (double)op.cout * op.cin * op.ksize * op.ksize * (op.kind == MIYOLO_OP_STEM ? 4 : es);
+    if (op.res.buf >= 0) by += mo * op.cout * es;
+  } else if (op.kind == MIYOLO_OP_MAXPOOL5) {
+    const miyolo_buf& sb = h->bufs[op.src[0].buf];
+    by = 2.0 * B * (H / sb.down) * (W / sb.down) * op.src[0].ch_cnt * es;
+  } else if (op.kind == MIYOLO_OP_DECODE) {
+    by = (double)B * total_anchors(h, H, W) * ((64 + h->desc.nc) + (4 + h->desc.nc)) * 4;
+  }
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return 0;
+}
+
+int miyolo_work(miyolo_handle h, int B, int H, int W, double* flops, double* bytes) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (int rc = check_shape(h, B, H, W)) return rc;
+  double fl = 0, by = 0;
+  for (int i = 0; i < (int)h->ops.size(); ++i) {
+    double f = 0, b = 0;
+    if (int rc = miyolo_op_work(h, i, B, H, W, &f, &b)) return rc;
+    fl += f; by += b;
+  }
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return 0;
+}
+
+}  // extern "C"

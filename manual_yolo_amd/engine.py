@@ -1,0 +1,303 @@
+"""ctypes binding of ``include/miyolo.h`` (the gfx950 HIP library) + device plumbing.
+
+This is the only place the product touches the native library.  PyTorch provides device
+memory (weights, workspace, outputs) and the stream; every compute step runs inside
+``libmiyolo.so``.  There is NO fallback: if the library is missing or no MI355X is visible,
+constructing an :class:`Engine` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .arch import OP_DECODE, Op, Program, View, build_program
+from .weights import K_ALIGN, build_weight_tensors
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmiyolo.so")
+DT_CODE = {"f32": 0, "f16": 1}
+
+
+class MiyoloError(RuntimeError):
+    pass
+
+
+class _View(C.Structure):
+    _fields_ = [("buf", C.c_int32), ("ch_off", C.c_int32), ("ch_cnt", C.c_int32), ("upsample", C.c_int32)]
+
+
+class _Buf(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("down", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("n_src", C.c_int32),
+                ("src", _View * 3), ("dst", _View), ("res", _View),
+                ("weight", C.c_int32), ("bias", C.c_int32),
+                ("level_stride", C.c_int32 * 3), ("reserved", C.c_int32 * 5)]
+
+
+class _Desc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("task", C.c_int32), ("dtype", C.c_int32), ("nc", C.c_int32),
+                ("reg_max", C.c_int32), ("max_stride", C.c_int32), ("n_bufs", C.c_int32),
+                ("n_ops", C.c_int32), ("n_weights", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+# name -> (restype, argtypes): every symbol include/miyolo.h declares
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "miyolo_abi_version": (_i, []),
+    "miyolo_k_align": (_i, [_i]),
+    "miyolo_create": (_i, [C.POINTER(_Desc), C.POINTER(_Buf), C.POINTER(_Op), C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "miyolo_destroy": (None, [_vp]),
+    "miyolo_last_error": (C.c_char_p, [_vp]),
+    "miyolo_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "miyolo_chunk": (_i, [_vp, _i, _i, _i]),
+    "miyolo_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "miyolo_detect": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "miyolo_head_raw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "miyolo_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "miyolo_classify": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "miyolo_read_buffer": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "miyolo_write_buffer": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "miyolo_run_ops": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "miyolo_work": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "miyolo_op_work": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "miyolo_profile_read": (_i, [_vp, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen ``libmiyolo.so`` (built in-tree by ``__graft_entry__.build()`` / ``csrc/build.sh``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MiyoloError(f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.miyolo_abi_version() != 1:
+        raise MiyoloError("libmiyolo.so ABI version mismatch")
+    for k, v in K_ALIGN.items():
+        if lib.miyolo_k_align(DT_CODE[k]) != v:
+            raise MiyoloError("weights.K_ALIGN disagrees with miyolo_k_align()")
+    _lib = lib
+    return lib
+
+
+def iou_threshold_f32(iou: float) -> float:
+    """torchvision's CPU nms compares the fp32 IoU against a C++ double threshold; the largest
+    float <= that double gives the identical decision in pure fp32 (oracle/post_ref.py)."""
+    t = np.float32(iou)
+    if float(t) > float(iou):
+        t = np.nextafter(t, np.float32(-np.inf))
+    return float(t)
+
+
+def _view(v: Optional[View]) -> _View:
+    if v is None:
+        return _View(-1, 0, 0, 0)
+    return _View(v.buf, v.ch_off, v.ch_cnt, v.upsample)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Engine:
+    """One model on one GPU.  Not re-entrant (one call in flight), as the C ABI states."""
+
+    def __init__(self, prog: Program, sd: Dict[str, torch.Tensor], bn_eps: float, dtype: str = "f16",
+                 device: Optional[int] = None, bgr_input: bool = True):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise MiyoloError("no GPU visible: the MI355X path has no CPU fallback")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.prog, self.dtype = prog, dtype
+        self.nc = prog.nc
+        cpu_w = build_weight_tensors(prog, sd, bn_eps, dtype, bgr_input)
+        self.weights = [w.to(self.device) for w in cpu_w]   # kept alive for the handle's lifetime
+        bufs = (_Buf * len(prog.bufs))(*[_Buf(c, d, dt, 0) for (c, d, dt) in prog.bufs])
+        ops = (_Op * len(prog.ops))()
+        for i, op in enumerate(prog.ops):
+            o = ops[i]
+            o.kind, o.ksize, o.stride, o.act, o.cin, o.cout = op.kind, op.ksize, op.stride, op.act, op.cin, op.cout
+            o.n_src = len(op.src)
+            for j in range(3):
+                o.src[j] = _view(op.src[j] if j < len(op.src) else None)
+            o.dst, o.res = _view(op.dst), _view(op.res)
+            o.weight, o.bias = op.weight, op.bias
+            for j in range(3):
+                o.level_stride[j] = op.level_stride[j]
+        desc = _Desc(1, 0 if prog.task == "detect" else 1, DT_CODE[dtype], prog.nc, 16, prog.max_stride,
+                     len(prog.bufs), len(prog.ops), len(self.weights))
+        wptrs = (C.c_void_p * len(self.weights))(*[w.data_ptr() for w in self.weights])
+        h = C.c_void_p()
+        rc = self.lib.miyolo_create(C.byref(desc), bufs, ops, wptrs, self.device_index, C.byref(h))
+        if rc != 0:
+            raise MiyoloError(f"miyolo_create failed ({rc}): {self.lib.miyolo_last_error(None).decode()}")
+        self.h = h
+        self._ws: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ plumbing
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.miyolo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise MiyoloError(f"{what} failed ({rc}): {self.lib.miyolo_last_error(self.h).decode()}")
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def set_option(self, key: str, value: int):
+        self._check(self.lib.miyolo_set_option(self.h, key.encode(), int(value)), "miyolo_set_option")
+
+    def workspace(self, B: int, H: int, W: int) -> torch.Tensor:
+        need = self.lib.miyolo_workspace_bytes(self.h, B, H, W)
+        if need == 0:
+            raise MiyoloError(f"bad shape B={B} H={H} W={W}: {self.lib.miyolo_last_error(self.h).decode()}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def chunk(self, B: int, H: int, W: int) -> int:
+        return self.lib.miyolo_chunk(self.h, B, H, W)
+
+    def _in(self, frames: torch.Tensor) -> Tuple[torch.Tensor, int, int, int]:
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+            raise MiyoloError("input must be uint8 [B,H,W,3]")
+        if frames.device != self.device:
+            frames = frames.to(self.device, non_blocking=True)
+        frames = frames.contiguous()
+        return frames, frames.shape[0], frames.shape[1], frames.shape[2]
+
+    def num_anchors(self, H: int, W: int) -> int:
+        return sum((H // s) * (W // s) for s in self.prog.strides)
+
+    # ------------------------------------------------------------------ hot path
+    def detect(self, frames: torch.Tensor, conf: float = 0.25, iou: float = 0.7, agnostic: bool = False,
+               max_det: int = 300, scale: Optional[torch.Tensor] = None, want_anchor: bool = True,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None):
+        """frames uint8 [B,H,W,3] on the GPU -> (dets [B,max_det,6], counts [B], anchor [B,max_det])."""
+        x, B, H, W = self._in(frames)
+        ws = self.workspace(B, H, W)
+        if out is None:
+            dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=self.device)
+            counts = torch.empty((B,), dtype=torch.int32, device=self.device)
+            anchor = torch.empty((B, max_det), dtype=torch.int32, device=self.device) if want_anchor else None
+        else:
+            dets, counts, anchor = out
+        rc = self.lib.miyolo_detect(self.h, x.data_ptr(), B, H, W, float(np.float32(conf)), iou_threshold_f32(iou),
+                                    int(agnostic), max_det, _ptr(scale), dets.data_ptr(), counts.data_ptr(),
+                                    _ptr(anchor), ws.data_ptr(), ws.numel(), self._stream())
+        self._check(rc, "miyolo_detect")
+        return dets, counts, anchor
+
+    def head_raw(self, frames: torch.Tensor) -> torch.Tensor:
+        x, B, H, W = self._in(frames)
+        ws = self.workspace(B, H, W)
+        y = torch.empty((B, 4 + self.nc, self.num_anchors(H, W)), dtype=torch.float32, device=self.device)
+        self._check(self.lib.miyolo_head_raw(self.h, x.data_ptr(), B, H, W, y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             self._stream()), "miyolo_head_raw")
+        return y
+
+    def nms(self, y: torch.Tensor, H: int, W: int, conf: float = 0.25, iou: float = 0.7, agnostic: bool = False,
+            max_det: int = 300, scale: Optional[torch.Tensor] = None):
+        y = y.to(self.device, torch.float32).contiguous()
+        B, _, A = y.shape
+        ws = self.workspace(B, H, W)
+        dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=self.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=self.device)
+        anchor = torch.empty((B, max_det), dtype=torch.int32, device=self.device)
+        rc = self.lib.miyolo_nms(self.h, y.data_ptr(), B, A, H, W, float(np.float32(conf)), iou_threshold_f32(iou),
+                                 int(agnostic), max_det, _ptr(scale), dets.data_ptr(), counts.data_ptr(),
+                                 anchor.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
+        self._check(rc, "miyolo_nms")
+        return dets, counts, anchor
+
+    def classify(self, frames: torch.Tensor):
+        x, B, H, W = self._in(frames)
+        ws = self.workspace(B, H, W)
+        logits = torch.empty((B, self.nc), dtype=torch.float32, device=self.device)
+        probs = torch.empty((B, self.nc), dtype=torch.float32, device=self.device)
+        self._check(self.lib.miyolo_classify(self.h, x.data_ptr(), B, H, W, logits.data_ptr(), probs.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), self._stream()), "miyolo_classify")
+        return logits, probs
+
+    # ------------------------------------------------------------------ parity taps
+    def buffer_shape(self, buf: int, B: int, H: int, W: int):
+        c, d, _ = self.prog.bufs[buf]
+        return (B, H // d, W // d, c)
+
+    def read_buffer(self, buf: int, B: int, H: int, W: int) -> torch.Tensor:
+        ws = self.workspace(B, H, W)
+        out = torch.empty(self.buffer_shape(buf, B, H, W), dtype=torch.float32, device=self.device)
+        self._check(self.lib.miyolo_read_buffer(self.h, buf, B, H, W, out.data_ptr(), ws.data_ptr(), self._stream()),
+                    "miyolo_read_buffer")
+        return out
+
+    def write_buffer(self, buf: int, x: torch.Tensor, H: int, W: int):
+        x = x.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        assert tuple(x.shape) == self.buffer_shape(buf, B, H, W), (tuple(x.shape), self.buffer_shape(buf, B, H, W))
+        ws = self.workspace(B, H, W)
+        self._check(self.lib.miyolo_write_buffer(self.h, buf, B, H, W, x.data_ptr(), ws.data_ptr(), self._stream()),
+                    "miyolo_write_buffer")
+
+    def run_ops(self, first: int, last: int, frames: Optional[torch.Tensor], B: int, H: int, W: int):
+        ws = self.workspace(B, H, W)
+        xin = None
+        if frames is not None:
+            xin, B, H, W = self._in(frames)
+        self._check(self.lib.miyolo_run_ops(self.h, first, last, _ptr(xin), B, H, W, ws.data_ptr(), ws.numel(),
+                                            self._stream()), "miyolo_run_ops")
+
+    def work(self, B: int, H: int, W: int) -> Tuple[float, float]:
+        fl, by = C.c_double(), C.c_double()
+        self._check(self.lib.miyolo_work(self.h, B, H, W, C.byref(fl), C.byref(by)), "miyolo_work")
+        return fl.value, by.value
+
+
+    def op_work(self, op: int, B: int, H: int, W: int) -> Tuple[float, float]:
+        fl, by = C.c_double(), C.c_double()
+        self._check(self.lib.miyolo_op_work(self.h, op, B, H, W, C.byref(fl), C.byref(by)), "miyolo_op_work")
+        return fl.value, by.value
+
+    def profile_read(self):
+        """[(op_index, conv_variant, ms)] of every op launch since profiling was switched on."""
+        n = self.lib.miyolo_profile_read(self.h, 0, None, None, None)
+        if n <= 0:
+            return []
+        ops = (C.c_int32 * n)(); cfg = (C.c_int32 * n)(); ms = (C.c_float * n)()
+        got = self.lib.miyolo_profile_read(self.h, n, ops, cfg, ms)
+        if got < 0:
+            self._check(got, "miyolo_profile_read")
+        return [(ops[i], cfg[i], ms[i]) for i in range(n)]
+
+
+def engine_from_weights(sd: Dict[str, torch.Tensor], meta: dict, dtype: str = "f16", device: Optional[int] = None,
+                        bgr_input: bool = True) -> Engine:
+    prog = build_program(meta["task"], meta["nc"], meta["scale"], meta.get("spec"), meta.get("nc_quirk", True))
+    return Engine(prog, sd, meta["bn_eps"], dtype, device, bgr_input)

@@ -1,0 +1,102 @@
+"""Host-side pre-processing in front of the GPU path (numpy/PIL; not the timed hot path).
+
+detect  : [3P] ultralytics LetterBox (reference ``detect.py:541`` -> predictor.preprocess):
+          aspect-preserving resize (cv2.INTER_LINEAR), pad value 114, to a multiple of the
+          stride (``auto`` / rect) or to the square ``imgsz``.  Frames stay uint8 BGR HWC:
+          the BGR->RGB flip, HWC->CHW and ``/255`` of the reference's preprocess are folded
+          into the stem kernel / its weight layout.
+classify: the torchvision transforms pickled in ``rank_classifier.pt`` (reference
+          ``detect.py:121``): PIL bilinear (antialiased) short-side resize to ``imgsz`` +
+          centre crop; ToTensor's ``/255`` again happens in the stem kernel.
+
+SURVEY.md section 8f ranks moving both onto the GPU as the next row after the hot path.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def bilinear_resize_u8(src: np.ndarray, dsize: Tuple[int, int]) -> np.ndarray:
+    """cv2.resize(src, (w, h), interpolation=cv2.INTER_LINEAR) semantics for uint8 HxWxC:
+    half-pixel centres, no antialiasing, 11-bit fixed-point weights, two-pass rounding."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = src.shape[:2]
+
+    def taps(dn: int, sn: int):
+        pos = (np.arange(dn, dtype=np.float64) + 0.5) * (sn / dn) - 0.5
+        i0 = np.floor(pos).astype(np.int64)
+        frac = (pos - i0).astype(np.float32)
+        under, over = i0 < 0, i0 >= sn - 1
+        frac[under] = 0.0
+        i0[under] = 0
+        frac[over] = 0.0
+        i0[over] = sn - 1
+        w1 = np.rint(frac * np.float32(2048.0)).astype(np.int32)
+        w0 = np.rint((np.float32(1.0) - frac) * np.float32(2048.0)).astype(np.int32)
+        return i0, np.minimum(i0 + 1, sn - 1), w0, w1
+
+    x0, x1, ax0, ax1 = taps(dw, sw)
+    y0, y1, by0, by1 = taps(dh, sh)
+    s = src.astype(np.int32)
+    horiz = s[:, x0] * ax0[None, :, None] + s[:, x1] * ax1[None, :, None]
+    top, bot = horiz[y0], horiz[y1]
+    out = (((by0[:, None, None] * (top >> 4)) >> 16) + ((by1[:, None, None] * (bot >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def letterbox(img: np.ndarray, new_shape: Tuple[int, int], auto: bool, stride: int = 32,
+              pad_value: int = 114) -> np.ndarray:
+    h0, w0 = img.shape[:2]
+    r = min(new_shape[0] / h0, new_shape[1] / w0)
+    new_unpad = (int(round(w0 * r)), int(round(h0 * r)))          # (w, h)
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    if auto:
+        dw, dh = dw % stride, dh % stride
+    dw, dh = dw / 2, dh / 2
+    if (w0, h0) != new_unpad:
+        img = bilinear_resize_u8(img, new_unpad)
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    out = np.full((img.shape[0] + top + bottom, img.shape[1] + left + right, 3), pad_value, dtype=np.uint8)
+    out[top:top + img.shape[0], left:left + img.shape[1]] = img
+    return out
+
+
+def letterbox_batch(frames: Sequence[np.ndarray], imgsz: Tuple[int, int], stride: int = 32) -> np.ndarray:
+    """[3P] DetectionPredictor.pre_transform: rect (``auto``) padding only when every frame of
+    the batch has the same shape, otherwise pad to the full square."""
+    same = len({f.shape for f in frames}) == 1
+    return np.stack([letterbox(f, imgsz, auto=same, stride=stride) for f in frames])
+
+
+def scale_params(net_hw: Tuple[int, int], orig_hw: Tuple[int, int]) -> List[float]:
+    """gain, pad_x, pad_y, orig_w, orig_h as [3P] scale_boxes derives them."""
+    gain = min(net_hw[0] / orig_hw[0], net_hw[1] / orig_hw[1])
+    pad_x = round((net_hw[1] - orig_hw[1] * gain) / 2 - 0.1)
+    pad_y = round((net_hw[0] - orig_hw[0] * gain) / 2 - 0.1)
+    return [gain, float(pad_x), float(pad_y), float(orig_hw[1]), float(orig_hw[0])]
+
+
+def classify_transform_bgr(img_bgr: np.ndarray, size: int) -> np.ndarray:
+    """BGR uint8 crop -> BGR uint8 size x size (resize/crop act per channel, so doing them in
+    BGR and letting the stem read BGR equals the reference's BGR->RGB -> PIL -> transforms)."""
+    from PIL import Image
+    im = Image.fromarray(np.ascontiguousarray(img_bgr))
+    w, h = im.size
+    if not ((w <= h and w == size) or (h <= w and h == size)):
+        if w < h:
+            im = im.resize((size, int(size * h / w)), Image.BILINEAR)
+        else:
+            im = im.resize((int(size * w / h), size), Image.BILINEAR)
+    w, h = im.size
+    if w < size or h < size:
+        pl = (size - w) // 2 if w < size else 0
+        pt = (size - h) // 2 if h < size else 0
+        canvas = Image.new("RGB", (max(w, size), max(h, size)))
+        canvas.paste(im, (pl, pt))
+        im = canvas
+        w, h = im.size
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    return np.asarray(im.crop((left, top, left + size, top + size)), dtype=np.uint8)

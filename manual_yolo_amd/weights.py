@@ -1,0 +1,83 @@
+"""State dict -> device tensors in the layouts ``include/miyolo.h`` documents.
+
+Host-side, one-time plumbing (torch on CPU, then one H2D copy per tensor); the reference does
+the equivalent inside ``YOLO(path)`` + ``AutoBackend(fuse=True)`` (reference
+``detect.py:20-21``): ``model.float().fuse()`` folds every BatchNorm into its conv
+([3P] ``fuse_conv_and_bn``: ``W' = W * g/sqrt(var+eps)``, ``b' = beta - mean*g/sqrt(var+eps)``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from .arch import Program, WeightRecipe
+
+K_ALIGN = {"f32": 32, "f16": 64}      # must equal miyolo_k_align(); checked in engine.py
+CHUNK_ELEMS = {"f32": 4, "f16": 8}
+TORCH_DTYPE = {"f32": torch.float32, "f16": torch.float16}
+
+
+def fold_conv(sd: Dict[str, torch.Tensor], r: WeightRecipe, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(weight [cout,cin,k,k] fp32, bias [cout] fp32) of one conv with its BN folded in."""
+    if r.fused_bn:
+        w = sd[r.prefix + ".conv.weight"].float()
+        g = sd[r.prefix + ".bn.weight"].float()
+        beta = sd[r.prefix + ".bn.bias"].float()
+        mean = sd[r.prefix + ".bn.running_mean"].float()
+        var = sd[r.prefix + ".bn.running_var"].float()
+        scale = g.div(torch.sqrt(eps + var))
+        wf = w * scale.view(-1, 1, 1, 1)
+        bf = beta - g.mul(mean).div(torch.sqrt(var + eps))
+        return wf, bf
+    return sd[r.prefix + ".weight"].float(), sd[r.prefix + ".bias"].float()
+
+
+def pack_conv_weight(wf: torch.Tensor, dtype: str) -> torch.Tensor:
+    """[cout,cin,kh,kw] -> [cout, kpad]: K = (ky, kx, cin) flattened, zero tail to K_ALIGN."""
+    cout, cin, kh, kw = wf.shape
+    flat = wf.permute(0, 2, 3, 1).reshape(cout, kh * kw * cin)
+    al = K_ALIGN[dtype]
+    kpad = (flat.shape[1] + al - 1) // al * al
+    out = torch.zeros((cout, kpad), dtype=torch.float32)
+    out[:, :flat.shape[1]] = flat
+    return out.to(TORCH_DTYPE[dtype]).contiguous()
+
+
+def pack_stem_weight(wf: torch.Tensor, bgr_input: bool) -> torch.Tensor:
+    """[cout,3,3,3] (cin = RGB as the model was trained) -> fp32 [ky,kx,c,cout]; with
+    ``bgr_input`` the c axis is reversed so the kernel can read BGR frames directly (the
+    reference flips BGR->RGB in its preprocess instead, [3P] ``im[..., ::-1]``)."""
+    if bgr_input:
+        wf = wf.flip(1)
+    return wf.permute(2, 3, 1, 0).reshape(27, wf.shape[0]).contiguous().float()
+
+
+def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float, dtype: str,
+                         bgr_input: bool = True) -> List[torch.Tensor]:
+    """One CPU tensor per ``prog.weights`` entry, ready for ``.to(device)``."""
+    out: List[torch.Tensor] = []
+    folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+    ce = CHUNK_ELEMS[dtype]
+    for r in prog.weights:
+        if r.kind in ("conv", "stem", "bias"):
+            if r.prefix not in folded:
+                folded[r.prefix] = fold_conv(sd, r, eps)
+            wf, bf = folded[r.prefix]
+            if r.kind == "conv":
+                for c in r.seg_channels:
+                    if c % ce:
+                        raise ValueError(f"{r.prefix}: input view of {c} channels is not a multiple of {ce} "
+                                         f"({dtype} needs 16-byte channel chunks)")
+                out.append(pack_conv_weight(wf, dtype))
+            elif r.kind == "stem":
+                out.append(pack_stem_weight(wf, bgr_input))
+            else:
+                out.append(bf.contiguous())
+        elif r.kind == "linear":
+            out.append(sd[r.prefix + ".weight"].float().contiguous())
+        elif r.kind == "linear_bias":
+            out.append(sd[r.prefix + ".bias"].float().contiguous())
+        else:
+            raise ValueError(r.kind)
+    return out

@@ -1,0 +1,66 @@
+"""CPU (gloo, world_size 2): the data-parallel shard + all-gather logic of manual_yolo_amd/dist.py."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from manual_yolo_amd.dist import all_gather_detections, shard_bounds, unpad
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(n_total, rank, world)
+    bl = (n_total + world - 1) // world
+    # fake per-frame detections: frame f has (f % 4) boxes whose first field is f
+    dets = torch.zeros((bl, 5, 6)); counts = torch.zeros((bl,), dtype=torch.int32)
+    for i, f in enumerate(range(lo, hi)):
+        counts[i] = f % 4
+        dets[i, : f % 4, 0] = float(f)
+    gd, gc = all_gather_detections(dets, counts)
+    q.put((rank, gd.clone(), gc.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    for n in (1, 7, 64, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_all_gather_detections_world2():
+    world, n_total = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bl = 4
+    for rank, gd, gc in got:
+        assert gd.shape == (world * bl, 5, 6) and gc.shape == (world * bl,)
+        frames = unpad(gd, gc)
+        # rank r's shard sits at rows [r*bl, r*bl + shard_len)
+        for r in range(world):
+            lo, hi = shard_bounds(n_total, r, world)
+            for i, f in enumerate(range(lo, hi)):
+                rows = frames[r * bl + i]
+                assert rows.shape[0] == f % 4 and bool((rows[:, 0] == f).all())
+    assert torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2])

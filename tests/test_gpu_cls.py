@@ -1,0 +1,92 @@
+"""-m gpu: yolov8n-cls (the reference's rank_classifier.pt weights) on the HIP path vs the oracle's
+golden logits and the reference's own known answers (63/67, 61/67)."""
+import numpy as np
+import pytest
+import torch
+
+from manual_yolo_amd.engine import engine_from_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines(rank_bundles):
+    out = {}
+    for tag in ("best", "last"):
+        sd, meta = rank_bundles[tag]
+        for dt in ("f32", "f16"):
+            out[tag, dt] = engine_from_weights(sd, meta, dt, 0, bgr_input=False)
+    return out
+
+
+def test_fp32_logits_within_1e4_of_cpu_path(engines, rank_valid):
+    """north_star: 'within 1e-4 on logits' - fp32 parity mode, all 67 reference crops."""
+    x = torch.from_numpy(rank_valid["pre_u8"]).cuda()
+    for tag in ("best", "last"):
+        logits, probs = engines[tag, "f32"].classify(x)
+        torch.cuda.synchronize()
+        le = np.abs(logits.cpu().numpy() - rank_valid[f"logits_{tag}"]).max()
+        pe = np.abs(probs.cpu().numpy() - rank_valid[f"probs_{tag}"]).max()
+        print(f"{tag}: max|dlogit|={le:.2e} max|dprob|={pe:.2e}")
+        assert le < 1e-4 and pe < 1e-5
+
+
+def test_known_answers_on_gpu(engines, rank_valid):
+    x = torch.from_numpy(rank_valid["pre_u8"]).cuda()
+    labels = rank_valid["labels"]
+    for dt in ("f32", "f16"):
+        _, p = engines["best", dt].classify(x)
+        assert int((p.argmax(1).cpu().numpy() == labels).sum()) == 63      # results.csv:21
+        _, p = engines["last", dt].classify(x)
+        assert int((p.argmax(1).cpu().numpy() == labels).sum()) == 61      # results.csv:22
+
+
+def test_fp16_logits_close(engines, rank_valid):
+    x = torch.from_numpy(rank_valid["pre_u8"]).cuda()
+    logits, probs = engines["best", "f16"].classify(x)
+    le = np.abs(logits.cpu().numpy() - rank_valid["logits_best"]).max()
+    print(f"f16 max|dlogit|={le:.3e}")
+    assert le < 5e-2          # fp16 activations: documented looser bound
+    assert np.array_equal(probs.argmax(1).cpu().numpy(), rank_valid["probs_best"].argmax(1))
+
+
+@pytest.mark.parametrize("B", [1, 3, 256])
+def test_batch_sizes_and_determinism(engines, rank_valid, B):
+    """Config 1 (B=1) and config 2 (B=256): every row equals the row computed in another batch."""
+    pre = rank_valid["pre_u8"]
+    idx = np.arange(B) % len(pre)
+    x = torch.from_numpy(pre[idx]).cuda()
+    eng = engines["best", "f32"]
+    l1, _ = eng.classify(x)
+    l2, _ = eng.classify(x)
+    assert torch.equal(l1, l2)
+    assert np.abs(l1.cpu().numpy() - rank_valid["logits_best"][idx]).max() < 1e-4
+
+
+def test_per_layer_taps_match_oracle(engines, rank_bundles, rank_valid):
+    """Localises a failing layer: every spec layer's activation vs the oracle's."""
+    from oracle.yolo_ref import RefYolo
+    sd, meta = rank_bundles["best"]
+    ref = RefYolo(sd, "classify", meta["nc"], meta["scale"], meta["bn_eps"])
+    pre = rank_valid["pre_u8"][:4]
+    _, feats = ref.forward(torch.from_numpy(pre).permute(0, 3, 1, 2).float() / 255, return_feats=True)
+    eng = engines["best", "f32"]
+    eng.classify(torch.from_numpy(pre).cuda())
+    for i, val in eng.prog.layer_out.items():
+        v = val.views[0]
+        got = eng.read_buffer(v.buf, 4, 64, 64).cpu().numpy()[..., v.ch_off:v.ch_off + v.ch_cnt]
+        want = feats[i].permute(0, 2, 3, 1).numpy()
+        err = np.abs(got - want).max()
+        print(f"layer {i}: max abs err {err:.2e} (|x|max {np.abs(want).max():.2f})")
+        assert err < 1e-4 * max(1.0, np.abs(want).max()), f"layer {i}"
+
+
+def test_bad_shapes_are_errors(engines):
+    from manual_yolo_amd.engine import MiyoloError
+    eng = engines["best", "f32"]
+    with pytest.raises(MiyoloError):
+        eng.classify(torch.zeros((1, 60, 64, 3), dtype=torch.uint8).cuda())      # not a multiple of 32
+    with pytest.raises(MiyoloError):
+        eng.classify(torch.zeros((1, 64, 64, 4), dtype=torch.uint8).cuda())
+    with pytest.raises(MiyoloError):
+        eng.detect(torch.zeros((1, 64, 64, 3), dtype=torch.uint8).cuda())          # wrong task

@@ -1,0 +1,107 @@
+"""-m gpu: the implicit-GEMM conv kernel (every tile shape, 3x3/1x1, stride 2, concat,
+upsample, residual, channel tails) against torch conv2d on the CPU, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import q, rel_err, run_conv
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-5, "f16": 2e-3}
+
+
+def ref_conv(x, w, b, s, act, res=None):
+    y = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w), torch.from_numpy(b), stride=s,
+                 padding=w.shape[2] // 2)
+    if act:
+        y = F.silu(y)
+    y = y.permute(0, 2, 3, 1).numpy()
+    return y + res if res is not None else y
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cin,cout,k,s,H,W,B", [
+    (48, 96, 3, 2, 32, 32, 2),      # yolov8m L1-like (cin 48: taps straddle K steps)
+    (48, 48, 3, 1, 20, 24, 1),      # L2 bottleneck
+    (96, 96, 3, 1, 16, 16, 2),
+    (192, 64, 3, 1, 12, 12, 1),     # head box branch
+    (288, 288, 3, 1, 10, 10, 1),    # L8 bottleneck (288 = 4.5 K steps per tap)
+    (384, 576, 3, 2, 8, 8, 1),      # L7
+    (96, 96, 1, 1, 16, 16, 1),      # C2f cv1
+    (576, 192, 1, 1, 8, 8, 2),
+    (64, 64, 1, 1, 12, 12, 1),
+    (16, 16, 3, 1, 16, 16, 3),      # classifier sizes
+    (16, 32, 3, 2, 32, 32, 2),
+    (256, 1280, 1, 1, 2, 2, 5),
+])
+def test_conv_layers(dtype, cin, cout, k, s, H, W, B):
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = q(rng.standard_normal((B, H // s, W // s, cout)).astype(np.float32), dtype)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, res, B, H, W)
+    ref = ref_conv(x, w, b, s, True, res)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL[dtype], rel_err(y, ref)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("wc,tc", [(2, 4), (2, 3), (1, 4), (1, 3), (1, 2), (1, 1)])
+@pytest.mark.parametrize("k", [1, 3])
+def test_every_tile_shape(dtype, wc, tc, k):
+    rng = np.random.default_rng(7)
+    cin, cout, H, W, B = 96, 112, 20, 12, 2           # cout 112: channel tail for every tile width
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, None, B, H, W, force=(wc, tc))
+    assert rel_err(y, ref_conv(x, w, b, 1, True)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_channel_slices_and_untouched_channels(dtype):
+    """Reads a slice of a wider buffer, writes a slice of a wider buffer (C2f layout)."""
+    rng = np.random.default_rng(3)
+    B, H, W, ld, off, cin, cout = 2, 12, 12, 192, 48, 48, 48
+    x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / 20).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96)
+    ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
+    assert rel_err(y[..., 96:144], ref) < TOL[dtype]
+    assert np.all(y[..., :96] == 7.0) and np.all(y[..., 144:] == 7.0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("c0,c1,up", [(576, 384, 1), (192, 384, 0), (64, 32, 1)])
+def test_concat_upsample_1x1(dtype, c0, c1, up):
+    """C2f.cv1 over cat(upsample(a), b) without materialising either (FPN layers 11-12, 14-15)."""
+    rng = np.random.default_rng(11)
+    B, H, W, cout = 2, 8, 12, 128
+    x0 = q(rng.standard_normal((B, H // 2, W // 2, c0) if up else (B, H, W, c0)).astype(np.float32), dtype)
+    x1 = q(rng.standard_normal((B, H, W, c1)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, c0 + c1, 1, 1)) / np.sqrt(c0 + c1)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x0, x1], w, b, [(c0, 0, c0, up), (c1, 0, c1, 0)], 1, 1, True, None, B, H, W)
+    x0u = np.repeat(np.repeat(x0, 2, 1), 2, 2) if up else x0
+    ref = ref_conv(np.concatenate([x0u, x1], -1), w, b, 1, True)
+    assert rel_err(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cout", [13, 64, 80])
+def test_head_final_conv_f32_out(dtype, cout):
+    """Detect's last 1x1 (bias, no activation) writes fp32 into a slice of the raw head map;
+    cout=13 exercises the scalar-store path (unaligned slice)."""
+    rng = np.random.default_rng(5)
+    B, H, W, cin = 1, 10, 10, 64
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 1, 1)) / 8).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 1, 1, False, None, B, H, W, dst_ld=64 + cout, dst_off=64,
+                 out_f32=True)
+    assert rel_err(y[..., 64:], ref_conv(x, w, b, 1, False)) < TOL[dtype]
+    assert np.all(y[..., :64] == 7.0)

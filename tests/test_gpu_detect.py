@@ -1,0 +1,193 @@
+"""-m gpu: detection path (backbone+neck+Detect head+decode+NMS) vs the CPU oracle.
+
+Detection parity is UNPINNED by the reference (poker_model.pt is absent): these tests pin the
+HIP path to the oracle on seeded synthetic weights."""
+import numpy as np
+import pytest
+import torch
+
+from manual_yolo_amd.engine import engine_from_weights
+from manual_yolo_amd.synth import synth_frames, synth_meta, synth_state_dict
+from oracle.post_ref import non_max_suppression, scale_boxes
+from oracle.yolo_ref import RefYolo
+
+pytestmark = pytest.mark.gpu
+NC = 64
+
+
+def _model(scale, dtype, quirk=False):
+    sd, meta = synth_state_dict("detect", NC, scale, 0, nc_quirk=quirk), synth_meta("detect", NC, scale, quirk)
+    return sd, meta, engine_from_weights(sd, meta, dtype, 0, bgr_input=False)
+
+
+def _oracle(sd, scale, frames, quirk=False, feats=False):
+    ref = RefYolo(sd, "detect", NC, scale, 1e-3, nc_quirk=quirk)
+    x = torch.from_numpy(frames).permute(0, 3, 1, 2).float() / 255
+    return ref.forward(x, return_feats=feats)
+
+
+@pytest.fixture(scope="module")
+def small():
+    sd, meta, eng = _model("n", "f32")
+    return sd, eng
+
+
+def test_per_layer_taps_small_model(small):
+    sd, eng = small
+    frames = synth_frames(2, 96, 128, seed=5)                    # rectangular, like letterboxed rect input
+    (y, raws), feats = _oracle(sd, "n", frames, feats=True)
+    got_y = eng.head_raw(torch.from_numpy(frames).cuda())
+    for i, val in eng.prog.layer_out.items():
+        if len(val.views) != 1 or val.views[0].upsample:
+            continue
+        v = val.views[0]
+        got = eng.read_buffer(v.buf, 2, 96, 128).cpu().numpy()[..., v.ch_off:v.ch_off + v.ch_cnt]
+        want = feats[i].permute(0, 2, 3, 1).numpy()
+        err = np.abs(got - want).max()
+        print(f"layer {i}: max abs err {err:.2e} (|x|max {np.abs(want).max():.2f})")
+        assert err < 2e-4 * max(1.0, np.abs(want).max()), f"layer {i}"
+    gy = got_y.cpu().numpy()
+    assert np.abs(gy[:, 4:] - y.numpy()[:, 4:]).max() < 1e-4
+    assert np.abs(gy[:, :4] - y.numpy()[:, :4]).max() < 1e-2
+
+
+def test_nc_quirk_architecture_runs(small):
+    """Ultralytics leaves a width equal to nc unscaled: the 'n' stem becomes 64 wide at nc=64."""
+    sd, meta, eng = _model("n", "f32", quirk=True)
+    frames = synth_frames(1, 64, 64, seed=2)
+    y, _ = _oracle(sd, "n", frames, quirk=True)
+    gy = eng.head_raw(torch.from_numpy(frames).cuda()).cpu().numpy()
+    assert np.abs(gy[:, 4:] - y.numpy()[:, 4:]).max() < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["noise", "blocks"])
+def test_yolov8m_640_head_and_nms_indices(kind):
+    """Config 3 shape: yolov8m, nc=64, 640x640, fp32 parity mode.  Scores within 1e-4 of the CPU
+    path, identical kept anchor indices after NMS (north_star)."""
+    sd, meta, eng = _model("m", "f32")
+    frames = synth_frames(2, 640, 640, seed=1, kind=kind)
+    y, _ = _oracle(sd, "m", frames)
+    y = y.numpy()
+    x = torch.from_numpy(frames).cuda()
+    gy = eng.head_raw(x).cpu().numpy()
+    es, eb = np.abs(gy[:, 4:] - y[:, 4:]).max(), np.abs(gy[:, :4] - y[:, :4]).max()
+    print(f"{kind}: max score err {es:.2e}, max box err {eb:.2e} px")
+    assert es < 1e-4 and eb < 2e-2
+    dets, counts, anchor = eng.detect(x, conf=0.25, iou=0.7)
+    outs, idxs = non_max_suppression(y, 0.25, 0.7)
+    for b in range(2):
+        n = int(counts[b])
+        assert n == len(idxs[b]), (n, len(idxs[b]))
+        assert np.array_equal(anchor[b, :n].cpu().numpy(), idxs[b])
+        d = dets[b, :n].cpu().numpy()
+        assert np.abs(d[:, :4] - outs[b][:, :4]).max() < 2e-2
+        assert np.abs(d[:, 4] - outs[b][:, 4]).max() < 1e-4
+        assert np.array_equal(d[:, 5], outs[b][:, 5])
+        assert np.all(dets[b, n:].cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("conf,iou,agn,max_det", [(0.25, 0.7, False, 300), (0.35, 0.7, False, 300),
+                                                  (0.5, 0.45, True, 300), (0.001, 0.6, False, 50),
+                                                  (0.25, 0.3, False, 1024)])
+def test_nms_bit_exact_on_identical_inputs(small, conf, iou, agn, max_det):
+    """Post-process alone, same y on both sides: kept indices, order, boxes and scores must be
+    IDENTICAL (integer/bit-exact bar), including score ties, dense clusters and the max_det cap."""
+    sd, eng = small
+    H = W = 320
+    A = eng.num_anchors(H, W)
+    rng = np.random.default_rng(0)
+    B = 3
+    y = np.zeros((B, 4 + NC, A), np.float32)
+    cx = rng.uniform(0, W, (B, A)); cy = rng.uniform(0, H, (B, A))
+    # clustered boxes: many anchors share a few centres, so IoUs straddle the threshold
+    centres = rng.uniform(40, 280, (B, 12, 2))
+    pick = rng.integers(0, 12, (B, A))
+    for b in range(B):
+        cx[b] = centres[b, pick[b], 0] + rng.normal(0, 6, A)
+        cy[b] = centres[b, pick[b], 1] + rng.normal(0, 6, A)
+    y[:, 0], y[:, 1] = cx, cy
+    y[:, 2] = rng.uniform(20, 90, (B, A)); y[:, 3] = rng.uniform(20, 90, (B, A))
+    sc = rng.uniform(0, 1, (B, NC, A)).astype(np.float32) ** 6
+    sc[0] = np.round(sc[0] * 16) / 16                       # image 0: heavy score ties
+    sc[2, :, : A // 2] = 0                                  # image 2: sparse
+    y[:, 4:] = sc
+    scale = torch.tensor([[0.5, 3.0, 10.0, 600.0, 500.0]] * B, dtype=torch.float32).cuda()
+    dets, counts, anchor = eng.nms(torch.from_numpy(y), H, W, conf, iou, agn, max_det, scale)
+    outs, idxs = non_max_suppression(y, conf, iou, agnostic=agn, max_det=max_det)
+    for b in range(B):
+        n = int(counts[b])
+        assert n == len(idxs[b])
+        assert np.array_equal(anchor[b, :n].cpu().numpy(), idxs[b])
+        want = outs[b].copy()
+        # same arithmetic as scale_boxes with an explicit (gain, pad): (x - pad) / gain, clip
+        want[:, [0, 2]] = np.clip((want[:, [0, 2]] - np.float32(3.0)) / np.float32(0.5), 0, 600.0)
+        want[:, [1, 3]] = np.clip((want[:, [1, 3]] - np.float32(10.0)) / np.float32(0.5), 0, 500.0)
+        assert np.array_equal(dets[b, :n].cpu().numpy(), want)
+
+
+def test_nms_empty_and_single(small):
+    sd, eng = small
+    H = W = 64
+    A = eng.num_anchors(H, W)
+    y = np.zeros((2, 4 + NC, A), np.float32)
+    y[1, 0:4, 5] = [30, 30, 10, 10]
+    y[1, 4 + 7, 5] = 0.9
+    dets, counts, anchor = eng.nms(torch.from_numpy(y), H, W)
+    assert counts.tolist() == [0, 1] and int(anchor[1, 0]) == 5
+    assert np.allclose(dets[1, 0].cpu().numpy(), [25, 25, 35, 35, 0.9, 7])
+    assert np.all(dets[0].cpu().numpy() == 0)
+
+
+def test_scale_boxes_matches_oracle(small):
+    """Letterbox undo inside the NMS kernel == oracle scale_boxes (930x1130 frame of detect.py:18)."""
+    from manual_yolo_amd.preprocess import scale_params
+    sd, eng = small
+    H, W = 640, 544
+    A = eng.num_anchors(H, W)
+    rng = np.random.default_rng(4)
+    y = np.zeros((1, 4 + NC, A), np.float32)
+    y[0, 0] = rng.uniform(0, W, A); y[0, 1] = rng.uniform(0, H, A)
+    y[0, 2] = rng.uniform(5, 40, A); y[0, 3] = rng.uniform(5, 40, A)
+    y[0, 4:] = (rng.uniform(0, 1, (NC, A)) ** 20).astype(np.float32)
+    scale = torch.tensor([scale_params((H, W), (1130, 930))], dtype=torch.float32).cuda()
+    dets, counts, anchor = eng.nms(torch.from_numpy(y), H, W, scale=scale)
+    outs, idxs = non_max_suppression(y)
+    n = int(counts[0])
+    assert n == len(idxs[0]) and n > 20
+    want = scale_boxes((H, W), outs[0][:, :4], (1130, 930))
+    assert np.abs(dets[0, :n, :4].cpu().numpy() - want).max() < 1e-3
+
+
+def test_batch_chunking_is_transparent(small):
+    sd, eng = small
+    frames = torch.from_numpy(synth_frames(5, 64, 96, seed=9)).cuda()
+    d1, c1, a1 = eng.detect(frames)
+    eng.set_option("max_chunk", 2)
+    d2, c2, a2 = eng.detect(frames)
+    y2 = eng.head_raw(frames)
+    eng.set_option("max_chunk", 0)
+    y1 = eng.head_raw(frames)
+    assert torch.equal(d1, d2) and torch.equal(c1, c2) and torch.equal(a1, a2) and torch.equal(y1, y2)
+
+
+def test_fp16_mode_agrees_on_detections():
+    """fp16 perf mode: same kept boxes as the CPU path up to borderline candidates (documented
+    tolerance: >= 97 % of kept anchors in common, boxes within 1 px, scores within 2e-2)."""
+    sd, meta, eng = _model("m", "f16")
+    frames = synth_frames(2, 640, 640, seed=1)
+    y, _ = _oracle(sd, "m", frames)
+    outs, idxs = non_max_suppression(y.numpy(), 0.25, 0.7)
+    dets, counts, anchor = eng.detect(torch.from_numpy(frames).cuda())
+    gy = eng.head_raw(torch.from_numpy(frames).cuda()).cpu().numpy()
+    print("f16 max score err", np.abs(gy[:, 4:] - y.numpy()[:, 4:]).max(), "box err", np.abs(gy[:, :4] - y.numpy()[:, :4]).max())
+    for b in range(2):
+        n = int(counts[b])
+        got = anchor[b, :n].cpu().numpy()
+        common = np.intersect1d(got, idxs[b])
+        frac = len(common) / max(len(idxs[b]), 1)
+        print(f"image {b}: kept {n} vs {len(idxs[b])}, common {frac:.3f}")
+        assert frac >= 0.97
+        gd = {a: d for a, d in zip(got, dets[b, :n].cpu().numpy())}
+        od = {a: d for a, d in zip(idxs[b], outs[b])}
+        for a in common:
+            assert np.abs(gd[a][:4] - od[a][:4]).max() < 1.0 and abs(gd[a][4] - od[a][4]) < 2e-2
