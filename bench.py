@@ -50,7 +50,8 @@ def cpu_baseline(args, sd, meta, frames_np):
     """Oracle (port of the Ultralytics CPU path) on the host cores, bounded sample."""
     from oracle.post_ref import non_max_suppression
     from oracle.yolo_ref import RefYolo
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
+    cores = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     task = meta["task"]
     ref = RefYolo(sd, task, meta["nc"], meta["scale"], meta["bn_eps"], nc_quirk=meta.get("nc_quirk", True))

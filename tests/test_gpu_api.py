@@ -43,10 +43,11 @@ def test_rank_classifier_drop_in(golden_dir, rank_valid):
 def test_detector_drop_in_surface():
     sd, meta = synth_state_dict("detect", 64, "n", 0), synth_meta("detect", 64, "n")
     model = YOLO((sd, meta))
-    frame = synth_frames(1, 930, 1130, seed=6)[0][:, :, ::-1].copy()       # detect.py:18 screen region, BGR
+    frame = synth_frames(1, 930, 1130, seed=6, kind="blocks")[0][:, :, ::-1].copy()   # detect.py:18-sized frame, BGR
     results = model(frame)[0]                                                # detect.py:541
     assert results.probs is None and results.boxes is not None and results.names is model.names
     n = len(results.boxes)
+    assert n > 0
     assert results.boxes.xyxy.shape == (n, 4) and results.boxes.id is None
     conf = results.boxes.conf.cpu().numpy()
     assert np.all(np.diff(conf) <= 0)                                        # keep order = descending confidence
