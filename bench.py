@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--workload", default="detect", choices=["detect", "classify"])
     ap.add_argument("--chunk", type=int, default=0, help="images per engine pass (0 = auto)")
+    ap.add_argument("--conv-impl", type=int, default=-1, help="0 register-staged conv, 1 LDS-DMA ring, 2 ring + halo kernel (default: engine default)")
+    ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (wrong results): see common.h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -99,6 +101,10 @@ def main():
     eng = engine_from_weights(sd, meta, args.dtype, local, bgr_input=False)
     if args.chunk:
         eng.set_option("max_chunk", args.chunk)
+    if args.conv_impl >= 0:
+        eng.set_option("conv_impl", args.conv_impl)
+    if args.ablate:
+        eng.set_option("ablate", args.ablate)
     frames_np = synth_frames(B, H, W, seed=1 + rank)
     frames = torch.from_numpy(frames_np).to(dev)
     max_det = 300
@@ -148,8 +154,15 @@ def main():
         eng.set_option("profile", 0)
         chunk = eng.chunk(B, H, W)
         per = {}
+        perop = {}
         for op, cfg, ms in recs:
-            k = ("conv_igemm<%s,k%d,wc%d,tc%d>" % (args.dtype, cfg // 100, (cfg // 10) % 10, cfg % 10)) if cfg else \
+            o = eng.prog.ops[op]
+            fl0, by0 = eng.op_work(op, min(chunk, B), H, W)
+            e0 = perop.setdefault(op, {"name": o.name, "kind": o.kind, "k": o.ksize, "s": o.stride, "cin": o.cin, "cout": o.cout,
+                                       "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl0, "bytes": by0})
+            e0["n"] += 1; e0["ms"] += ms
+        for op, cfg, ms in recs:
+            k = ("%s<%s,k%d,wc%d,tc%d>" % ("conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm", args.dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)) if cfg else \
                 {0: "stem", 2: "maxpool5", 3: "decode", 4: "cls_head"}.get(eng.prog.ops[op].kind, "op")
             fl, by = eng.op_work(op, min(chunk, B), H, W)
             e = per.setdefault(k, [0, 0.0, 0.0, 0.0])
@@ -172,9 +185,17 @@ def main():
                         "avg_launch_ms": round(ms / n, 4)}
         if args.profile_out and rank == 0:
             with open(args.profile_out, "w") as f:
-                json.dump({k: {"launches": v[0], "ms": v[1], "flop": v[2], "bytes": v[3],
-                               "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[1] else 0,
-                               "gbs": (v[3] / (v[1] * 1e-3) / 1e9) if v[1] else 0} for k, v in per.items()}, f, indent=1)
+                agg = {k: {"launches": v[0], "ms": v[1], "flop": v[2], "bytes": v[3],
+                           "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[1] else 0,
+                           "gbs": (v[3] / (v[1] * 1e-3) / 1e9) if v[1] else 0} for k, v in per.items()}
+                layers = []
+                for op in sorted(perop):
+                    e0 = perop[op]
+                    avg = e0["ms"] / e0["n"]
+                    e0.update(avg_ms=avg, tflops=e0["flop"] / (avg * 1e-3) / 1e12 if avg else 0,
+                              gbs=e0["bytes"] / (avg * 1e-3) / 1e9 if avg else 0)
+                    layers.append(e0)
+                json.dump({"by_kernel": agg, "by_op": layers}, f, indent=1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

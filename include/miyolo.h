@@ -111,9 +111,10 @@ int miyolo_k_align(int dtype);
 
 /* Replaces: YOLO(path) model construction + AutoBackend(fuse=True) (detect.py:20-21).
  * `weights[i]` are device pointers; conv weights are BN-folded, laid out [cout][kpad]
- * (see miyolo_k_align) in `desc->dtype`; biases fp32 [cout]; the stem weight is fp32
- * [ky][kx][c][cout] with the 1/255 input scale NOT folded (the kernel divides the uint8
- * pixel by 255 as the reference's preprocess does); CLS_HEAD weight fp32 [nc][c]. */
+ * (see miyolo_k_align) in `desc->dtype`; biases fp32 [cout]; the stem weight is [cout][32] in
+ * `desc->dtype`, K' = 8q+j with q<3: (ky=q, byte j = kx*3+c, j<8), q=3: j<3 -> (ky=j,kx=2,c=2),
+ * rest zero; the 1/255 input scale is NOT folded (the kernel divides the uint8 pixel by 255 as
+ * the reference's preprocess does); CLS_HEAD weight fp32 [nc][c]. */
 int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_op* ops,
                   const void* const* weights, int device, miyolo_handle* out);
 void miyolo_destroy(miyolo_handle h);
@@ -160,7 +161,9 @@ int miyolo_chunk(miyolo_handle h, int B, int H, int W);
 
 /* Options: "max_chunk" (images per pass, 0 = automatic), "force_wc"/"force_tc" (pin the conv
  * tile shape: waves along channels 1|2, 16-channel tiles per wave 1..4; tests and tuning),
- * "profile" (see miyolo_profile_read). */
+ * "profile" (see miyolo_profile_read), "conv_impl" (0: register-staged double-buffered conv
+ * kernel; 1: LDS-DMA 3-stage ring kernel; 2 (default): as 1, plus the LDS halo-tile kernel for
+ * 3x3 stride-1 convolutions). */
 int miyolo_set_option(miyolo_handle h, const char* key, int value);
 
 /* Debug/parity taps (B must not exceed miyolo_chunk): copy activation buffer `buf` out as /
@@ -175,8 +178,8 @@ int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int 
 
 /* Bench support: with option "profile" = 1 every op launch is bracketed by hipEvents on the
  * call's stream; miyolo_profile_read synchronises on them and returns, per recorded launch,
- * the op index, the conv kernel variant (ksize*100 + waves_along_channels*10 + tiles, 0 for
- * non-conv ops) and the duration in ms.  Returns the number of records; passing NULL arrays
+ * the op index, the conv kernel variant (conv_impl*1000 + ksize*100 + waves_along_channels*10 +
+ * tiles, 0 for non-conv ops) and the duration in ms.  Returns the number of records; passing NULL arrays
  * only counts, passing arrays consumes the records.  Not for the hot path. */
 int miyolo_profile_read(miyolo_handle h, int max_records, int32_t* op_index, int32_t* cfg, float* ms);
 /* Algorithmic flops (2*MAC) and compulsory bytes of ONE op for a B x H x W batch. */

@@ -19,6 +19,9 @@ template <> struct DT<half_t> { static constexpr int CE = 8; static constexpr in
 // SiLU exactly as torch computes it in fp32: x / (1 + exp(-x)).
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+// fp16 path: v_exp_f32 + v_rcp_f32 (about 1 ulp each) instead of an IEEE divide - the result is
+// rounded to fp16 right after, and the divide was a third of the conv epilogue's instructions.
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // A channel-slice view resolved to a device pointer for one launch.
 struct SrcDesc {
@@ -47,7 +50,55 @@ struct ConvArgs {
   int32_t cin, cout, ksize, stride, act;
   int32_t M, kpad, nk;              // M = B*Hout*Wout; kpad = padded K per weight row; nk = kpad / BK
   int32_t vec_ok;                   // epilogue may use 4-channel vector stores
+  int32_t res_vec;                  // residual view is 4-channel aligned (vector loads)
+  int32_t ablate;                   // timing experiments only (results wrong): 1 no tile DMA in the loop, 2 no MFMA, 4 no LDS reads
   int32_t exact;                    // 1: accurate expf in SiLU (fp32 parity mode)
 };
+
+// Shared conv epilogue tail: residual add (after the activation, as Bottleneck does) and the store
+// of 4 consecutive output channels n..n+3 of pixel m.  v[] already holds bias + activation.
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, int m, int n, float (&v)[4]) {
+  if (a.res) {
+    const T* rp = reinterpret_cast<const T*>(a.res) + ((size_t)m * a.res_ld + a.res_choff + n);
+    if (a.res_vec) {
+      if constexpr (sizeof(T) == 4) {
+        const float4 r = *reinterpret_cast<const float4*>(rp);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      } else {
+        const f16x4 r = *reinterpret_cast<const f16x4*>(rp);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.cout) v[r] += (float)rp[r];
+    }
+  }
+  if (a.out_f32) {
+    float* dp = reinterpret_cast<float*>(a.dst) + ((size_t)m * a.dst_ld + a.dst_choff + n);
+    if (a.vec_ok) {
+      *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.cout) dp[r] = v[r];
+    }
+  } else {
+    T* dp = reinterpret_cast<T*>(a.dst) + ((size_t)m * a.dst_ld + a.dst_choff + n);
+    if (a.vec_ok) {
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<f16x4*>(dp) = hv;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.cout) dp[r] = (T)v[r];
+    }
+  }
+}
 
 }  // namespace miyolo

@@ -246,39 +246,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = acc[i][j][r] + bv[r];
-        if (a.act) x = a.exact ? silu_exact(x) : silu_f(x);
+        if (a.act) x = a.exact ? silu_exact(x) : silu_fast(x);
         v[r] = x;
       }
-      if (a.res) {
-        const T* rp = reinterpret_cast<const T*>(a.res) + ((size_t)m * a.res_ld + a.res_choff + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.cout) v[r] += to_f32(rp[r]);
-      }
-      if (a.out_f32) {
-        float* dp = reinterpret_cast<float*>(a.dst) + ((size_t)m * a.dst_ld + a.dst_choff + n);
-        if (a.vec_ok) {
-          *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.cout) dp[r] = v[r];
-        }
-      } else {
-        T* dp = reinterpret_cast<T*>(a.dst) + ((size_t)m * a.dst_ld + a.dst_choff + n);
-        if (a.vec_ok) {
-          if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *reinterpret_cast<f16x4*>(dp) = hv;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.cout) dp[r] = (T)v[r];
-        }
-      }
+      epilogue_store<T>(a, m, n, v);
     }
   }
 }

@@ -8,67 +8,106 @@ namespace miyolo {
 // ------------------------------------------------------------------------------------
 // Stem: conv3x3 s2 p1 over the uint8 frame with the `/255` of the reference's preprocess
 // ([3P] DetectionPredictor.preprocess: im.float(); im /= 255) folded in, + bias + SiLU.
-// K = 27 is too thin for the matrix cores to matter: the layer is bound by writing
-// 2*cout bytes per output pixel, so each thread produces one output pixel for all output
-// channels, 16 at a time, with wave-uniform weights (scalar loads -> SGPR operands).
-// Weight layout: fp32 [27 = ky,kx,c][cout].
+//
+// The layer is bound by WRITING its output (2*cout bytes per pixel against 6.75 input bytes);
+// the 27-deep contraction is padded to one 32-deep MFMA step so the arithmetic disappears
+// behind the stores.  K' order (what `lane>>4 = q` holds, 8 values each):
+//     q = 0,1,2 : kernel row ky = q, the first 8 of its 9 consecutive input bytes (kx*3 + c)
+//     q = 3     : byte 8 (kx=2, c=2) of rows ky = 0,1,2, then five zeros
+// i.e. a lane reads 8 adjacent bytes of one image row - NHWC uint8 makes a kernel row's three
+// pixels contiguous.  Weights arrive as [cout][32] in the same K' order (weights.py).
+// One wave = 16 output pixels x all output channels per iteration; out-of-image taps are
+// out-of-range buffer loads (zero).
 struct StemArgs {
   const uint8_t* in;   // [B,H,W,3]
-  const float* w;      // [27][cout]
+  const void* w;       // [cout][32] T, K' order
   const float* bias;   // [cout]
   void* out;           // [B,H/2,W/2,cout] T
   int32_t B, H, W, Ho, Wo, cout, act, exact;
+  uint32_t in_bytes;
 };
 
-template <typename T>
+template <typename T, int TCS>
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+  constexpr int CE = DT<T>::CE;
+  const int lane = threadIdx.x & 63, frow = lane & 15, q = lane >> 4;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const long total = (long)a.B * a.Ho * a.Wo;
-  const long m = (long)blockIdx.x * 256 + threadIdx.x;
-  if (m >= total) return;
-  const int wo = (int)(m % a.Wo);
-  const long t = m / a.Wo;
-  const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
-  float x[27];
+  const long ntiles = (total + 15) / 16;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.in), 0, a.in_bytes, 0x00020000);
+  // weight fragments: A[ch = tc*16 + frow][k' = 8q .. 8q+7]
+  uint4 wf[TCS][sizeof(T) == 4 ? 2 : 1];
+  const T* wp = reinterpret_cast<const T*>(a.w);
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int hi = 2 * ho - 1 + ky;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int wi = 2 * wo - 1 + kx;
-      const bool v = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      const uint8_t* p = a.in + (((long)b * a.H + (v ? hi : 0)) * a.W + (v ? wi : 0)) * 3;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = v ? (float)p[c] / 255.0f : 0.0f;
-    }
+  for (int tc = 0; tc < TCS; ++tc) {
+    const T* p = wp + (tc * 16 + frow) * 32 + q * 8;
+    wf[tc][0] = *reinterpret_cast<const uint4*>(p);
+    if constexpr (sizeof(T) == 4) wf[tc][1] = *reinterpret_cast<const uint4*>(p + 4);
   }
-  T* op = reinterpret_cast<T*>(a.out) + m * a.cout;
-  for (int cg = 0; cg < a.cout; cg += 16) {
-    float acc[16];
+  float bv[TCS][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int tc = 0; tc < TCS; ++tc)
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      const float* wk = a.w + k * a.cout + cg;
+    for (int r = 0; r < 4; ++r) bv[tc][r] = a.bias[tc * 16 + q * 4 + r];
+
+  for (long tile = wave_global; tile < ntiles; tile += nwaves) {
+    const long m = tile * 16 + frow;
+    const bool vm = m < total;
+    const long mm = vm ? m : 0;
+    const int wo = (int)(mm % a.Wo);
+    const long t2 = mm / a.Wo;
+    const int ho = (int)(t2 % a.Ho), b = (int)(t2 / a.Ho);
+    const int wi0 = 2 * wo - 1, hi0 = 2 * ho - 1;
+    float x[8];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = fmaf(x[k], wk[j], acc[j]);
+    for (int j = 0; j < 8; ++j) {
+      // q<3: row hi0+q, byte j of the 9-byte run;  q==3: row hi0+j, byte 8 (j<3)
+      const int hi = (q < 3) ? hi0 + q : hi0 + j;
+      const int bo = (q < 3) ? j : 8;
+      const int wi = wi0 + bo / 3;
+      const bool ok = vm && (q < 3 || j < 3) && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const uint32_t off = ok ? (uint32_t)((((long)b * a.H + hi) * a.W + wi0) * 3 + bo) : 0x80000000u;
+      const uint32_t u = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+      x[j] = a.exact ? (float)u / 255.0f : (float)u * (1.0f / 255.0f);   // f16: rounded to half right after
     }
+    f32x4 acc[TCS];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float v = acc[j] + a.bias[cg + j];
-      if (a.act) v = a.exact ? silu_exact(v) : silu_f(v);
-      acc[j] = v;
-    }
+    for (int tc = 0; tc < TCS; ++tc) acc[tc] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int j = 0; j < 16; j += 4)
-        *reinterpret_cast<float4*>(op + cg + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+      for (int tc = 0; tc < TCS; ++tc) {
+        const float* w0 = reinterpret_cast<const float*>(&wf[tc][0]);
+        const float* w1 = reinterpret_cast<const float*>(&wf[tc][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x[j], acc[tc], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], x[4 + j], acc[tc], 0, 0, 0);
+      }
     } else {
+      f16x8 xb;
 #pragma unroll
-      for (int j = 0; j < 16; j += 8) {
-        f16x8 hv;
+      for (int j = 0; j < 8; ++j) xb[j] = (half_t)x[j];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hv[q] = (half_t)acc[j + q];
-        *reinterpret_cast<f16x8*>(op + cg + j) = hv;
+      for (int tc = 0; tc < TCS; ++tc)
+        acc[tc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&wf[tc][0]), xb, acc[tc], 0, 0, 0);
+    }
+    if (vm) {
+      T* op = reinterpret_cast<T*>(a.out) + m * a.cout + q * 4;
+#pragma unroll
+      for (int tc = 0; tc < TCS; ++tc) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = acc[tc][r] + bv[tc][r];
+          if (a.act) y = a.exact ? silu_exact(y) : silu_fast(y);
+          v[r] = y;
+        }
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(op + tc * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<f16x4*>(op + tc * 16) = hv;
+        }
       }
     }
   }

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,8 @@
 
 #include "common.h"
 #include "conv_igemm.h"
+#include "conv_dma.h"
+#include "conv_halo.h"
 #include "kernels_misc.h"
 #include "nms.h"
 
@@ -40,6 +43,8 @@ struct miyolo_engine {
   int device = 0;
   int max_chunk = 0;        // 0 = automatic
   int force_wc = 0, force_tc = 0;
+  int conv_impl = 2;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+  int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   int profile = 0;          // 1: bracket every op launch with hipEvents (bench/roofline only)
   struct ProfRec { int op, cfg; hipEvent_t e0, e1; };
   std::vector<ProfRec> prof;
@@ -87,6 +92,35 @@ hipError_t set_conv_attrs_ks() {
   if ((e = set_conv_attr<T, KS, 1, 3>()) != hipSuccess) return e;
   if ((e = set_conv_attr<T, KS, 1, 2>()) != hipSuccess) return e;
   return set_conv_attr<T, KS, 1, 1>();
+}
+
+template <typename T, int KS, int WC, int TC>
+hipError_t set_dma_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<T, KS, WC, TC>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes<WC, TC>());
+}
+template <typename T, int KS>
+hipError_t set_dma_attrs_ks() {
+  hipError_t e;
+  if ((e = set_dma_attr<T, KS, 2, 4>()) != hipSuccess) return e;
+  if ((e = set_dma_attr<T, KS, 2, 3>()) != hipSuccess) return e;
+  if ((e = set_dma_attr<T, KS, 1, 4>()) != hipSuccess) return e;
+  if ((e = set_dma_attr<T, KS, 1, 3>()) != hipSuccess) return e;
+  if ((e = set_dma_attr<T, KS, 1, 2>()) != hipSuccess) return e;
+  return set_dma_attr<T, KS, 1, 1>();
+}
+
+template <typename T>
+hipError_t set_halo_attrs() {
+  hipError_t e;
+  const int lds = (int)halo_lds_bytes(8);
+#define MIYOLO_HALO_ATTR(WC, TC)                                                                       \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, WC, TC>),            \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  MIYOLO_HALO_ATTR(2, 4) MIYOLO_HALO_ATTR(2, 3) MIYOLO_HALO_ATTR(1, 4) MIYOLO_HALO_ATTR(1, 3)
+  MIYOLO_HALO_ATTR(1, 2) MIYOLO_HALO_ATTR(1, 1)
+#undef MIYOLO_HALO_ATTR
+  return hipSuccess;
 }
 
 int nms_lds_bytes(int max_det) { return ((max_det * 5 * 4 + 15) & ~15) + kNmsLdsKeys * 8; }
@@ -162,15 +196,24 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       const miyolo_buf& ob = h->bufs[op.dst.buf];
       StemArgs a;
       a.in = static_cast<const uint8_t*>(in);
-      a.w = static_cast<const float*>(h->weights[op.weight]);
+      a.w = h->weights[op.weight];
       a.bias = static_cast<const float*>(h->weights[op.bias]);
       a.out = buf_ptr(h, p, op.dst.buf, in, ws);
       a.B = Bc; a.H = H; a.W = W; a.Ho = H / ob.down; a.Wo = W / ob.down;
       a.cout = op.cout; a.act = op.act; a.exact = (h->desc.dtype == MIYOLO_F32);
-      if (op.cout % 16 || op.dst.ch_off != 0 || ob.channels != op.cout || ob.down != 2)
-        return fail(h, MIYOLO_ERR_UNSUPPORTED, "stem: cout=%d must be a multiple of 16 and own its buffer", op.cout);
-      const long total = (long)Bc * a.Ho * a.Wo;
-      hipLaunchKernelGGL(stem_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+      if ((size_t)Bc * H * W * 3 >= ((size_t)1 << 31)) return fail(h, MIYOLO_ERR_SHAPE, "input batch exceeds 2 GiB per pass");
+      a.in_bytes = (uint32_t)((size_t)Bc * H * W * 3);
+      if (op.cout % 16 || op.cout > 80 || op.dst.ch_off != 0 || ob.channels != op.cout || ob.down != 2)
+        return fail(h, MIYOLO_ERR_UNSUPPORTED, "stem: cout=%d must be a multiple of 16 (<= 80) and own its buffer", op.cout);
+      const long ntiles = ((long)Bc * a.Ho * a.Wo + 15) / 16;
+      const unsigned grid = (unsigned)std::min<long>((ntiles + 3) / 4, 256 * 8);
+      switch (op.cout / 16) {
+        case 1: hipLaunchKernelGGL((stem_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((stem_kernel<T, 2>), dim3(grid), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((stem_kernel<T, 3>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((stem_kernel<T, 4>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((stem_kernel<T, 5>), dim3(grid), dim3(256), 0, s, a); break;
+      }
       break;
     }
     case MIYOLO_OP_CONV: {
@@ -218,7 +261,11 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.wbytes = (uint32_t)((size_t)op.cout * a.kpad * sizeof(T));
       a.vec_ok = (op.cout % 4 == 0) && (ob.channels % 4 == 0) && (op.dst.ch_off % 4 == 0);
       a.exact = (h->desc.dtype == MIYOLO_F32);
-      HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
+      a.ablate = h->ablate;
+      a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
+      if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
+      else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
+      else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
       break;
     }
     case MIYOLO_OP_MAXPOOL5: {
@@ -276,9 +323,13 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
 int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   if (op.kind != MIYOLO_OP_CONV) return 0;
   const miyolo_buf& ob = h->bufs[op.dst.buf];
-  ConvCfg c = pick_conv_cfg(op.cout, (long)p.B * (p.H / ob.down) * (p.W / ob.down));
+  const long M = (long)p.B * (p.H / ob.down) * (p.W / ob.down);
+  const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
+                    halo_xi(p.W / ob.down) <= 8;
+  const int impl = halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
+  ConvCfg c = impl == 2 ? pick_halo_cfg(op.cout, M) : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
   if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
-  return op.ksize * 100 + c.wc * 10 + c.tc;      // e.g. 324 = conv_igemm_kernel<T,3,2,4>
+  return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 2323 = conv_halo_kernel<T,2,3>
 }
 
 int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
@@ -372,6 +423,12 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_conv_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_conv_attrs_ks<half_t, 1>();
   if (e == hipSuccess) e = set_conv_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_dma_attrs_ks<float, 1>();
+  if (e == hipSuccess) e = set_dma_attrs_ks<float, 3>();
+  if (e == hipSuccess) e = set_dma_attrs_ks<half_t, 1>();
+  if (e == hipSuccess) e = set_dma_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_halo_attrs<float>();
+  if (e == hipSuccess) e = set_halo_attrs<half_t>();
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_greedy_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, nms_lds_bytes(1024));
@@ -393,6 +450,8 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "force_wc")) { h->force_wc = value; return 0; }
   if (!strcmp(key, "force_tc")) { h->force_tc = value; return 0; }
   if (!strcmp(key, "profile")) { h->profile = value; return 0; }
+  if (!strcmp(key, "conv_impl")) { h->conv_impl = value; return 0; }
+  if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }
   return fail(h, MIYOLO_ERR_ARG, "unknown option %s", key);
 }
 

@@ -44,13 +44,21 @@ def pack_conv_weight(wf: torch.Tensor, dtype: str) -> torch.Tensor:
     return out.to(TORCH_DTYPE[dtype]).contiguous()
 
 
-def pack_stem_weight(wf: torch.Tensor, bgr_input: bool) -> torch.Tensor:
-    """[cout,3,3,3] (cin = RGB as the model was trained) -> fp32 [ky,kx,c,cout]; with
-    ``bgr_input`` the c axis is reversed so the kernel can read BGR frames directly (the
-    reference flips BGR->RGB in its preprocess instead, [3P] ``im[..., ::-1]``)."""
+def pack_stem_weight(wf: torch.Tensor, bgr_input: bool, dtype: str) -> torch.Tensor:
+    """[cout,3,3,3] (cin = RGB as the model was trained) -> [cout][32] in the stem kernel's K'
+    order (kernels_misc.h): k' = 8q + j; q<3: kernel row ky=q, byte j = kx*3 + c of its 9-byte
+    run (j < 8); q=3: j<3 -> (ky=j, kx=2, c=2), rest zero.  With ``bgr_input`` the c axis is
+    reversed so the kernel reads BGR frames directly (the reference flips BGR->RGB in its
+    preprocess instead, [3P] ``im[..., ::-1]``)."""
     if bgr_input:
         wf = wf.flip(1)
-    return wf.permute(2, 3, 1, 0).reshape(27, wf.shape[0]).contiguous().float()
+    cout = wf.shape[0]
+    run = wf.permute(0, 2, 3, 1).reshape(cout, 3, 9).float()      # [cout][ky][kx*3 + c]
+    out = torch.zeros((cout, 32), dtype=torch.float32)
+    for q in range(3):
+        out[:, 8 * q:8 * q + 8] = run[:, q, :8]
+    out[:, 24:27] = run[:, :, 8]
+    return out.to(TORCH_DTYPE[dtype]).contiguous()
 
 
 def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float, dtype: str,
@@ -71,7 +79,7 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
                                          f"({dtype} needs 16-byte channel chunks)")
                 out.append(pack_conv_weight(wf, dtype))
             elif r.kind == "stem":
-                out.append(pack_stem_weight(wf, bgr_input))
+                out.append(pack_stem_weight(wf, bgr_input, dtype))
             else:
                 out.append(bf.contiguous())
         elif r.kind == "linear":

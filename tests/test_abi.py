@@ -70,7 +70,7 @@ def test_program_and_weight_layouts():
             if r.kind == "conv":
                 assert w.shape[1] % K_ALIGN[dt] == 0 and w.dtype == (torch.float16 if dt == "f16" else torch.float32)
             if r.kind == "stem":
-                assert tuple(w.shape) == (27, 48)
+                assert tuple(w.shape) == (48, 32)
     # upsample / concat never become ops: only 3 op kinds besides conv appear
     assert {o.kind for o in prog.ops} == {0, 1, 2, 3}
     cls = build_program("classify", 13, "n")

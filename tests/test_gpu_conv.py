@@ -21,6 +21,10 @@ def ref_conv(x, w, b, s, act, res=None):
     return y + res if res is not None else y
 
 
+IMPLS = [0, 1, 2]   # 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("cin,cout,k,s,H,W,B", [
     (48, 96, 3, 2, 32, 32, 2),      # yolov8m L1-like (cin 48: taps straddle K steps)
@@ -36,48 +40,51 @@ def ref_conv(x, w, b, s, act, res=None):
     (16, 32, 3, 2, 32, 32, 2),
     (256, 1280, 1, 1, 2, 2, 5),
 ])
-def test_conv_layers(dtype, cin, cout, k, s, H, W, B):
+def test_conv_layers(dtype, cin, cout, k, s, H, W, B, impl):
     rng = np.random.default_rng(cin * 1000 + cout + k)
     x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
     w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
     res = q(rng.standard_normal((B, H // s, W // s, cout)).astype(np.float32), dtype)
-    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, res, B, H, W)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, res, B, H, W, impl=impl)
     ref = ref_conv(x, w, b, s, True, res)
     assert y.shape == ref.shape
     assert rel_err(y, ref) < TOL[dtype], rel_err(y, ref)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("wc,tc", [(2, 4), (2, 3), (1, 4), (1, 3), (1, 2), (1, 1)])
 @pytest.mark.parametrize("k", [1, 3])
-def test_every_tile_shape(dtype, wc, tc, k):
+def test_every_tile_shape(dtype, wc, tc, k, impl):
     rng = np.random.default_rng(7)
-    cin, cout, H, W, B = 96, 112, 20, 12, 2           # cout 112: channel tail for every tile width
+    cin, cout, H, W, B = 96, 112, 20, 28, 2           # cout 112: channel tail for every tile width; M = 1120: M tail
     x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
     w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
-    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, None, B, H, W, force=(wc, tc))
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, None, B, H, W, force=(wc, tc), impl=impl)
     assert rel_err(y, ref_conv(x, w, b, 1, True)) < TOL[dtype]
 
 
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
-def test_channel_slices_and_untouched_channels(dtype):
+def test_channel_slices_and_untouched_channels(dtype, impl):
     """Reads a slice of a wider buffer, writes a slice of a wider buffer (C2f layout)."""
     rng = np.random.default_rng(3)
     B, H, W, ld, off, cin, cout = 2, 12, 12, 192, 48, 48, 48
     x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
     w = q((rng.standard_normal((cout, cin, 3, 3)) / 20).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
-    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96)
+    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96, impl=impl)
     ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
     assert rel_err(y[..., 96:144], ref) < TOL[dtype]
     assert np.all(y[..., :96] == 7.0) and np.all(y[..., 144:] == 7.0)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("c0,c1,up", [(576, 384, 1), (192, 384, 0), (64, 32, 1)])
-def test_concat_upsample_1x1(dtype, c0, c1, up):
+def test_concat_upsample_1x1(dtype, c0, c1, up, impl):
     """C2f.cv1 over cat(upsample(a), b) without materialising either (FPN layers 11-12, 14-15)."""
     rng = np.random.default_rng(11)
     B, H, W, cout = 2, 8, 12, 128
@@ -85,15 +92,16 @@ def test_concat_upsample_1x1(dtype, c0, c1, up):
     x1 = q(rng.standard_normal((B, H, W, c1)).astype(np.float32), dtype)
     w = q((rng.standard_normal((cout, c0 + c1, 1, 1)) / np.sqrt(c0 + c1)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
-    y = run_conv(dtype, [x0, x1], w, b, [(c0, 0, c0, up), (c1, 0, c1, 0)], 1, 1, True, None, B, H, W)
+    y = run_conv(dtype, [x0, x1], w, b, [(c0, 0, c0, up), (c1, 0, c1, 0)], 1, 1, True, None, B, H, W, impl=impl)
     x0u = np.repeat(np.repeat(x0, 2, 1), 2, 2) if up else x0
     ref = ref_conv(np.concatenate([x0u, x1], -1), w, b, 1, True)
     assert rel_err(y, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("cout", [13, 64, 80])
-def test_head_final_conv_f32_out(dtype, cout):
+def test_head_final_conv_f32_out(dtype, cout, impl):
     """Detect's last 1x1 (bias, no activation) writes fp32 into a slice of the raw head map;
     cout=13 exercises the scalar-store path (unaligned slice)."""
     rng = np.random.default_rng(5)
@@ -102,6 +110,29 @@ def test_head_final_conv_f32_out(dtype, cout):
     w = q((rng.standard_normal((cout, cin, 1, 1)) / 8).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
     y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 1, 1, False, None, B, H, W, dst_ld=64 + cout, dst_off=64,
-                 out_f32=True)
+                 out_f32=True, impl=impl)
     assert rel_err(y[..., 64:], ref_conv(x, w, b, 1, False)) < TOL[dtype]
     assert np.all(y[..., :64] == 7.0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,B,force", [
+    (96, 96, 20, 20, 3, None),        # M = 1200: tiles straddle frames, M tail
+    (48, 48, 12, 160, 1, None),       # widest yolov8m@640 map (W=160), cin 48 = 1.5 chunks
+    (16, 32, 8, 320, 1, (1, 2)),      # W=320 (1280 input): XI = 8, the largest halo that fits
+    (16, 16, 4, 382, 1, (1, 1)),      # widest eligible row (W=382)
+    (192, 192, 18, 22, 2, (2, 4)),    # rect inputs such as 544 wide
+    (32, 32, 6, 62, 2, (2, 3)),       # R + 1 = 383..384: zero row is the last LDS row of the halo buffer
+    (64, 64, 40, 40, 1, (1, 4)),
+    (288, 96, 6, 10, 5, (2, 3)),
+    (32, 16, 4, 4, 70, (1, 1)),       # many tiny frames per tile
+])
+def test_halo_kernel_shapes(dtype, cin, cout, H, W, B, force):
+    """conv_halo.h: shifted LDS windows, zero-row masking at frame borders, halo pieces."""
+    rng = np.random.default_rng(cin + cout + W)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, res, B, H, W, force=force, impl=2)
+    assert rel_err(y, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
