@@ -111,7 +111,8 @@ int miyolo_k_align(int dtype);
 
 /* Replaces: YOLO(path) model construction + AutoBackend(fuse=True) (detect.py:20-21).
  * `weights[i]` are device pointers; conv weights are BN-folded, laid out [cout][kpad]
- * (see miyolo_k_align) in `desc->dtype`; biases fp32 [cout]; the stem weight is [cout][32] in
+ * (see miyolo_k_align) in `desc->dtype`; biases fp32 [cout] zero padded to a multiple of 128
+ * floats; the stem weight is [cout][32] in
  * `desc->dtype`, K' = 8q+j with q<3: (ky=q, byte j = kx*3+c, j<8), q=3: j<3 -> (ky=j,kx=2,c=2),
  * rest zero; the 1/255 input scale is NOT folded (the kernel divides the uint8 pixel by 255 as
  * the reference's preprocess does); CLS_HEAD weight fp32 [nc][c]. */
@@ -162,8 +163,8 @@ int miyolo_chunk(miyolo_handle h, int B, int H, int W);
 /* Options: "max_chunk" (images per pass, 0 = automatic), "force_wc"/"force_tc" (pin the conv
  * tile shape: waves along channels 1|2, 16-channel tiles per wave 1..4; tests and tuning),
  * "profile" (see miyolo_profile_read), "conv_impl" (0: register-staged double-buffered conv
- * kernel; 1: LDS-DMA 3-stage ring kernel; 2 (default): as 1, plus the LDS halo-tile kernel for
- * 3x3 stride-1 convolutions). */
+ * kernel; 1: LDS-DMA 3-stage ring kernel; 2: as 1, plus the LDS halo-tile kernel for 3x3
+ * stride-1 convolutions; 3 (default): persistent LDS-DMA ring kernel). */
 int miyolo_set_option(miyolo_handle h, const char* key, int value);
 
 /* Debug/parity taps (B must not exceed miyolo_chunk): copy activation buffer `buf` out as /

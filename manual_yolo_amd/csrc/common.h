@@ -51,6 +51,8 @@ struct ConvArgs {
   int32_t M, kpad, nk;              // M = B*Hout*Wout; kpad = padded K per weight row; nk = kpad / BK
   int32_t vec_ok;                   // epilogue may use 4-channel vector stores
   int32_t res_vec;                  // residual view is 4-channel aligned (vector loads)
+  uint32_t mg_hw_mul, mg_hw_shift;  // magic division by Hout*Wout (conv_dmap.h host_magic)
+  uint32_t mg_w_mul, mg_w_shift;    // magic division by Wout
   int32_t ablate;                   // timing experiments only (results wrong): 1 no tile DMA in the loop, 2 no MFMA, 4 no LDS reads
   int32_t exact;                    // 1: accurate expf in SiLU (fp32 parity mode)
 };

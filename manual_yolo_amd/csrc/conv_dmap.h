@@ -1,0 +1,291 @@
+// Implicit-GEMM convolution, third generation: PERSISTENT workgroups over the LDS-DMA ring.
+//
+// Same tile math as conv_dma.h.  What the ablation timings of that kernel showed
+// (profiles/r01_conv_dma_ablation.md): the MFMAs and LDS reads are already hidden, and 35-65 % of
+// a launch is per-workgroup fixed cost that nothing overlaps when one 512-thread workgroup
+// owns a CU - launch, index arithmetic, the latency of the first two tile DMAs, the epilogue's
+// store drain - multiplied by 6-25 rounds of workgroups per launch.  Here a launch has at most
+// one workgroup per CU and each walks a static list of tiles:
+//   * the DMA stream (tile, K step) runs two steps ahead of the MFMA stream ACROSS tile
+//     boundaries: while tile t is in its epilogue, the first two stages of tile t+1 are
+//     already landing;
+//   * per-tile index arithmetic is a few multiply-high "magic" divisions done in the shadow of
+//     the K loop (host supplies the constants), instead of ~40-instruction integer divides;
+//   * the ring slot counter and the vmcnt accounting simply continue across tiles.
+// Tiles are dealt so that the tiles sharing an activation tile run on one XCD in the same time
+// slot.  Exit condition: a static trip count per workgroup (no queues, no spinning).
+#pragma once
+#include "common.h"
+#include "conv_dma.h"
+
+namespace miyolo {
+
+__device__ __forceinline__ uint32_t magic_div(uint32_t x, uint32_t mul, uint32_t shift) {
+  // floor(x / d) for x < 2^31; (mul, shift) from host_magic(d); d == 1 is encoded as mul == 0
+  return mul ? (__umulhi(x, mul) >> shift) : x;
+}
+
+template <typename T, int KS, int WC, int TC>
+__global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
+  constexpr int CE = DT<T>::CE;
+  constexpr int WP = 8 / WC;
+  constexpr int TPW = DMA_BM / (WP * 16);
+  constexpr int BM = DMA_BM;
+  constexpr int BN = WC * TC * 16;
+  constexpr int BNP = (BN + 63) / 64 * 64;
+  constexpr int ROWS = BM + BNP;
+  constexpr int NI = ROWS / 64;
+  constexpr int XI = BM / 64;
+  constexpr int STAGE = ROWS * ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WC, wc = wave % WC;
+
+  // ---- static tile list of this workgroup: slot k -> tile k*G + (b%8)*(G/8) + b/8 (G = grid,
+  // a multiple of 8): the G/8 workgroups of one XCD group take consecutive tiles, and
+  // consecutive tiles share the pixel tile (channel tile index runs fastest)
+  const int NB = (a.cout + BN - 1) / BN;
+  const int MB = (a.M + BM - 1) / BM;
+  const int ntiles = MB * NB;
+  const int G = gridDim.x;
+  const int first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int my_tiles = (first < ntiles) ? (ntiles - first + G - 1) / G : 0;
+  if (my_tiles == 0) return;
+  const int total_steps = my_tiles * a.nk;
+
+  const v4i_t rs0 = make_srd(a.src[0].ptr, a.src[0].bytes);
+  const v4i_t rs1 = make_srd(a.src[1].ptr, a.src[1].bytes);
+  const v4i_t rsw = make_srd(a.w, a.wbytes);
+  const uint32_t lds_base = (uint32_t)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  constexpr uint32_t kOob = 0x80000000u;
+
+  const int rsub = lane >> 3;
+  const int cg = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int ct0 = a.src[0].ch_cnt / CE;
+  const int ct1 = (a.nsrc > 1) ? a.src[1].ch_cnt / CE : 0;
+  const int HWo = a.Hout * a.Wout;
+
+  // ---- DMA-side state: the tile whose stages are being issued
+  int32_t xoff0[XI];
+  int32_t xoff1[KS == 1 ? XI : 1];
+  uint32_t xmask[XI];
+  uint32_t woff[NI - XI];
+  int tap = 0, coff = 0;
+  int d_tile = first, d_ks = 0, d_slot = 0, d_issued = 0;
+
+  auto setup_tile = [&](int tile) {      // per-lane row state of `tile` (magic divisions only)
+    const int mb = tile / NB, nb = tile - mb * NB;       // wave-uniform: scalar unit
+    const int m0 = mb * BM, n0 = nb * BN;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int m = m0 + 8 * (wave + 8 * i) + rsub;
+      const bool vm = m < a.M;
+      const uint32_t mm = vm ? (uint32_t)m : 0u;
+      const int b = (int)magic_div(mm, a.mg_hw_mul, a.mg_hw_shift);
+      const uint32_t rem = mm - (uint32_t)b * (uint32_t)HWo;
+      const int ho = (int)magic_div(rem, a.mg_w_mul, a.mg_w_shift);
+      const int wo = (int)rem - ho * a.Wout;
+      if constexpr (KS == 3) {
+        const int hi0 = ho * a.stride - 1, wi0 = wo * a.stride - 1;
+        xoff0[i] = (((b * a.src[0].h + hi0) * a.src[0].w + wi0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
+        // rows/cols of the 3x3 window inside the image -> 9-bit tap mask as an outer product
+        const uint32_t hm = (hi0 >= 0 ? 1u : 0u) | 2u | ((hi0 + 2 < a.Hin) ? 4u : 0u);
+        const uint32_t wm = (wi0 >= 0 ? 1u : 0u) | 2u | ((wi0 + 2 < a.Win) ? 4u : 0u);
+        uint32_t msk = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
+        xmask[i] = vm ? msk : 0u;
+      } else {
+        const int h0 = a.src[0].up ? (ho >> 1) : ho, w0 = a.src[0].up ? (wo >> 1) : wo;
+        xoff0[i] = (((b * a.src[0].h + h0) * a.src[0].w + w0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
+        const int h1 = a.src[1].up ? (ho >> 1) : ho, w1 = a.src[1].up ? (wo >> 1) : wo;
+        xoff1[i] = (((b * a.src[1].h + h1) * a.src[1].w + w1) * a.src[1].ld + a.src[1].ch_off) * (int)sizeof(T);
+        xmask[i] = vm ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI - XI; ++i) {
+      const int row = 8 * (wave + 8 * i) + rsub, n = n0 + row;
+      woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cg * 16) : kOob;
+    }
+    tap = 0; coff = cg;
+    if constexpr (KS == 3) {
+      tap = cg / ct0;
+      coff = cg - tap * ct0;
+    }
+  };
+
+  // issue the NI DMAs of the DMA stream's next (tile, K step); branch-free validity (conv_dma.h)
+  auto issue_next = [&]() {
+    const uint32_t st = lds_base + (uint32_t)(d_slot * STAGE + wave * 1024);
+    const int ks = d_ks;
+    if constexpr (KS == 3) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int32_t toff = ((ky * a.src[0].w + kx) * a.src[0].ld + coff * CE) * (int)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const uint32_t bit = (xmask[i] >> tap) & 1u;
+        const uint32_t off = (uint32_t)(xoff0[i] + toff) | ((bit ^ 1u) << 31);
+        lds_dma16(rs0, st + i * 8192, off);
+      }
+      coff += 8;
+      while (coff >= ct0) { coff -= ct0; ++tap; }
+    } else {
+      const int q = ks * 8 + cg;
+      const bool seg1 = (ks * 8) >= ct0;
+      const int cq = seg1 ? q - ct0 : q;
+      const int lim = seg1 ? ct1 : ct0;
+      const uint32_t kvb = ((uint32_t)(cq - lim)) >> 31;
+      const int32_t toff = cq * CE * (int)sizeof(T);
+      if (!seg1) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const uint32_t off = (uint32_t)(xoff0[i] + toff) | (((kvb & xmask[i]) ^ 1u) << 31);
+          lds_dma16(rs0, st + i * 8192, off);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const uint32_t off = (uint32_t)(xoff1[i] + toff) | (((kvb & xmask[i]) ^ 1u) << 31);
+          lds_dma16(rs1, st + i * 8192, off);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI - XI; ++i) {
+      const uint32_t off = woff[i] + (uint32_t)(ks * 128);
+      lds_dma16(rsw, st + BM * ROW_BYTES + i * 8192, off);
+    }
+    d_slot = (d_slot == 2) ? 0 : d_slot + 1;
+    ++d_issued;
+    if (++d_ks == a.nk) {                 // DMA stream moves on to this workgroup's next tile
+      d_ks = 0;
+      d_tile += G;
+      if (d_tile < ntiles) setup_tile(d_tile);
+    }
+  };
+
+  f32x4 acc[TC][TPW];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  auto compute = [&](int slot) {
+    const unsigned char* xs = smem + slot * STAGE;
+    const unsigned char* ws = xs + BM * ROW_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[TC], bf[TPW];
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+        af[i] = *reinterpret_cast<const uint4*>(ws + lds_off((wc * TC + i) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < TPW; ++j)
+        bf[j] = *reinterpret_cast<const uint4*>(xs + lds_off((wp * TPW + j) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  // ---- stream: prologue issues two stages, then one barrier + one issue + one compute per step
+  setup_tile(d_tile);
+  issue_next();
+  if (total_steps > 1) issue_next();
+
+  int c_tile = first, c_ks = 0, c_slot = 0;
+  for (int c = 0; c < total_steps; ++c) {
+    if (c + 1 < total_steps) {
+      if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (d_issued < total_steps) issue_next();
+    compute(c_slot);
+    c_slot = (c_slot == 2) ? 0 : c_slot + 1;
+    if (++c_ks == a.nk) {
+      // ---- epilogue of tile c_tile (the next tile's first stages are already in flight)
+      const int mb = c_tile / NB, nb = c_tile - mb * NB;
+      const int m0 = mb * BM, n0 = nb * BN;
+      // bias through the SCALAR unit (wave-uniform address -> s_load, lgkmcnt): a vector load
+      // here would make the compiler wait vmcnt(0) and drain the next tile's DMAs in flight.
+      // The bias array is padded to a multiple of 128 floats by the host (weights.py).
+      const float* __restrict__ bias = a.bias;
+#pragma unroll
+      for (int i = 0; i < TC; ++i) {
+        const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + i) * 16);
+        const int n = nt + fq * 4;
+        v4i_t s0, s1, s2, s3;            // 16 consecutive biases of this 16-channel tile, in SGPRs
+        const float* bp = bias + nt;
+        asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
+                     "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const int m = m0 + (wp * TPW + j) * 16 + frow;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][r] + bv[r];
+            if (a.act) x = a.exact ? silu_exact(x) : silu_fast(x);
+            v[r] = x;
+            acc[i][j][r] = 0.f;
+          }
+          if (n < a.cout && m < a.M) epilogue_store<T>(a, m, n, v);
+        }
+      }
+      c_ks = 0;
+      c_tile += G;
+    }
+  }
+}
+
+// host: magic constants for floor(x/d), x < 2^31 (Granlund-Montgomery, 31-bit dividend):
+// l = ceil(log2 d), mul = floor(2^(31+l)/d) + 1, q = umulhi(x, mul) >> (l-1); d == 1 -> mul = 0.
+inline void host_magic(uint32_t d, uint32_t* mul, uint32_t* shift) {
+  if (d <= 1) { *mul = 0; *shift = 0; return; }
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  const unsigned long long m = (1ull << (31 + l)) / d + 1;
+  *mul = (uint32_t)m;
+  *shift = l - 1;
+}
+
+template <typename T, int KS, int WC, int TC>
+inline hipError_t launch_dmap_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
+  constexpr int BN = WC * TC * 16;
+  const size_t lds = dma_lds_bytes<WC, TC>();
+  const long mbk = ((long)a.M + DMA_BM - 1) / DMA_BM, nb = (a.cout + BN - 1) / BN;
+  long grid = std::min<long>(mbk * nb, ncu);
+  grid = (grid + 7) / 8 * 8;             // the tile dealing assumes a multiple of 8
+  hipLaunchKernelGGL((conv_dmap_kernel<T, KS, WC, TC>), dim3((unsigned)grid), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T, int KS>
+inline hipError_t launch_dmap_ks(const ConvArgs& a, ConvCfg c, hipStream_t s, int ncu) {
+  if (c.wc == 2 && c.tc == 4) return launch_dmap_cfg<T, KS, 2, 4>(a, s, ncu);
+  if (c.wc == 2 && c.tc == 3) return launch_dmap_cfg<T, KS, 2, 3>(a, s, ncu);
+  if (c.wc == 1 && c.tc == 4) return launch_dmap_cfg<T, KS, 1, 4>(a, s, ncu);
+  if (c.wc == 1 && c.tc == 3) return launch_dmap_cfg<T, KS, 1, 3>(a, s, ncu);
+  if (c.wc == 1 && c.tc == 2) return launch_dmap_cfg<T, KS, 1, 2>(a, s, ncu);
+  return launch_dmap_cfg<T, KS, 1, 1>(a, s, ncu);
+}
+
+template <typename T>
+inline hipError_t launch_conv_dmap(const ConvArgs& a, hipStream_t s, int ncu, int force_wc = 0, int force_tc = 0) {
+  ConvCfg c = pick_dma_cfg(a.cout, a.M);
+  if (force_wc > 0 && force_tc > 0) c = {force_wc, force_tc};
+  if (a.ksize == 3) return launch_dmap_ks<T, 3>(a, c, s, ncu);
+  return launch_dmap_ks<T, 1>(a, c, s, ncu);
+}
+
+}  // namespace miyolo

@@ -17,6 +17,7 @@
 #include "conv_igemm.h"
 #include "conv_dma.h"
 #include "conv_halo.h"
+#include "conv_dmap.h"
 #include "kernels_misc.h"
 #include "nms.h"
 
@@ -43,7 +44,9 @@ struct miyolo_engine {
   int device = 0;
   int max_chunk = 0;        // 0 = automatic
   int force_wc = 0, force_tc = 0;
-  int conv_impl = 2;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+  int conv_impl = 3;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for
+                            // 3x3 s1 (conv_halo.h); 3: persistent LDS-DMA ring (conv_dmap.h)
+  int ncu = 256;
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   int profile = 0;          // 1: bracket every op launch with hipEvents (bench/roofline only)
   struct ProfRec { int op, cfg; hipEvent_t e0, e1; };
@@ -108,6 +111,18 @@ hipError_t set_dma_attrs_ks() {
   if ((e = set_dma_attr<T, KS, 1, 3>()) != hipSuccess) return e;
   if ((e = set_dma_attr<T, KS, 1, 2>()) != hipSuccess) return e;
   return set_dma_attr<T, KS, 1, 1>();
+}
+
+template <typename T, int KS>
+hipError_t set_dmap_attrs_ks() {
+  hipError_t e;
+#define MIYOLO_DMAP_ATTR(WC, TC)                                                                        \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dmap_kernel<T, KS, WC, TC>),         \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes<WC, TC>())) != hipSuccess) return e;
+  MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
+  MIYOLO_DMAP_ATTR(1, 2) MIYOLO_DMAP_ATTR(1, 1)
+#undef MIYOLO_DMAP_ATTR
+  return hipSuccess;
 }
 
 template <typename T>
@@ -263,7 +278,10 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.exact = (h->desc.dtype == MIYOLO_F32);
       a.ablate = h->ablate;
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
-      if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
+      host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
+      host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
+      if (h->conv_impl == 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      else if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
       else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
       else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
       break;
@@ -326,8 +344,8 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   const long M = (long)p.B * (p.H / ob.down) * (p.W / ob.down);
   const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
                     halo_xi(p.W / ob.down) <= 8;
-  const int impl = halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
-  ConvCfg c = impl == 2 ? pick_halo_cfg(op.cout, M) : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
+  const int impl = h->conv_impl == 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
+  ConvCfg c = impl == 2 ? pick_halo_cfg(op.cout, M) : impl >= 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
   if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
   return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 2323 = conv_halo_kernel<T,2,3>
 }
@@ -407,6 +425,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   miyolo_engine* h = new miyolo_engine();
   h->desc = *desc;
   h->device = device;
+  h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   h->bufs.assign(bufs, bufs + desc->n_bufs);
   h->ops.assign(ops, ops + desc->n_ops);
   h->weights.assign(weights, weights + desc->n_weights);
@@ -427,6 +446,10 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_dma_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dma_attrs_ks<half_t, 1>();
   if (e == hipSuccess) e = set_dma_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_dmap_attrs_ks<float, 1>();
+  if (e == hipSuccess) e = set_dmap_attrs_ks<float, 3>();
+  if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 1>();
+  if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 3>();
   if (e == hipSuccess) e = set_halo_attrs<float>();
   if (e == hipSuccess) e = set_halo_attrs<half_t>();
   if (e == hipSuccess)

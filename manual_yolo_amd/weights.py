@@ -81,7 +81,9 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
             elif r.kind == "stem":
                 out.append(pack_stem_weight(wf, bgr_input, dtype))
             else:
-                out.append(bf.contiguous())
+                bp = torch.zeros(((bf.numel() + 127) // 128 * 128,), dtype=torch.float32)   # padded: the persistent
+                bp[:bf.numel()] = bf                                                        # conv kernel s_loads 16 at a time
+                out.append(bp)
         elif r.kind == "linear":
             out.append(sd[r.prefix + ".weight"].float().contiguous())
         elif r.kind == "linear_bias":
