@@ -183,6 +183,9 @@ int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int 
  * tiles, 0 for non-conv ops) and the duration in ms.  Returns the number of records; passing NULL arrays
  * only counts, passing arrays consumes the records.  Not for the hot path. */
 int miyolo_profile_read(miyolo_handle h, int max_records, int32_t* op_index, int32_t* cfg, float* ms);
+/* Timing-experiment builds only (-DMIYOLO_ABLATE=1, option "dbg_op"): per-wave cycle stamps of the
+ * persistent conv kernel for one op; `out` is a HOST buffer of 256*8*8 uint64. Synchronises. */
+int miyolo_debug_stamps(miyolo_handle h, unsigned long long* out);
 /* Algorithmic flops (2*MAC) and compulsory bytes of ONE op for a B x H x W batch. */
 int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* flops, double* bytes);
 

@@ -3,6 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-experiment switches (profiles/r01_conv_dma_ablation.md) are compiled in only with
+// -DMIYOLO_ABLATE=1 (csrc/build.sh ablate); the shipped kernels carry none of their branches.
+#ifndef MIYOLO_ABLATE
+#define MIYOLO_ABLATE 0
+#endif
+#define ABL(bit) (MIYOLO_ABLATE && (a.ablate & (bit)))
+#if MIYOLO_ABLATE
+#define STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
 namespace miyolo {
 
 typedef _Float16 half_t;
@@ -53,6 +65,7 @@ struct ConvArgs {
   int32_t res_vec;                  // residual view is 4-channel aligned (vector loads)
   uint32_t mg_hw_mul, mg_hw_shift;  // magic division by Hout*Wout (conv_dmap.h host_magic)
   uint32_t mg_w_mul, mg_w_shift;    // magic division by Wout
+  unsigned long long* dbg;          // MIYOLO_ABLATE builds: per-workgroup cycle stamps (conv_dmap.h)
   int32_t ablate;                   // timing experiments only (results wrong): 1 no tile DMA in the loop, 2 no MFMA, 4 no LDS reads
   int32_t exact;                    // 1: accurate expf in SiLU (fp32 parity mode)
 };

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  if (a.ablate & 64) return;
+  if ABL(64) return;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave / WC, wc = wave % WC;
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 af[TC], bf[TPW];
-      if (!(a.ablate & 4)) {
+      if (!ABL(4)) {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
           af[i] = *reinterpret_cast<const uint4*>(ws + lds_off((wc * TC + i) * 16 + frow, kk * 4 + fq));
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) bf[j] = make_uint4(lane, j, kk, slot);
       }
-      if (!(a.ablate & 2)) {
+      if (!ABL(2)) {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a) {
   };
 
   // ---- 3-stage ring
-  const int nk_eff = (a.ablate & 32) ? 0 : a.nk;
+  const int nk_eff = ABL(32) ? 0 : a.nk;
   if (nk_eff > 0) issue(0, 0);
   if (nk_eff > 1) issue(1, 1);
   int slot = 0;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (ks + 2 < a.nk && !(a.ablate & 1)) issue(ks + 2, slot >= 1 ? slot - 1 : 2);   // (slot + 2) % 3
+    if (ks + 2 < a.nk && !ABL(1)) issue(ks + 2, slot >= 1 ? slot - 1 : 2);   // (slot + 2) % 3
     compute(slot);
     slot = (slot == 2) ? 0 : slot + 1;
   }
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(512) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = acc[i][j][r] + bv[r];
-        if (a.act && !(a.ablate & 16)) x = a.exact ? silu_exact(x) : silu_fast(x);
+        if (a.act && !ABL(16)) x = a.exact ? silu_exact(x) : silu_fast(x);
         v[r] = x;
       }
-      if (!(a.ablate & 8) || v[0] == 123.456f) epilogue_store<T>(a, m, n, v);
+      if (!ABL(8) || v[0] == 123.456f) epilogue_store<T>(a, m, n, v);
     }
   }
 }

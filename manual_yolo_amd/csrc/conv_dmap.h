@@ -67,12 +67,34 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   const int ct1 = (a.nsrc > 1) ? a.src[1].ch_cnt / CE : 0;
   const int HWo = a.Hout * a.Wout;
 
+  // ---- K table (built once per workgroup, reused by every tile): for K step ks and chunk column
+  // c the activation chunk sits `kofs` bytes after the row's base pointer and belongs to tap /
+  // segment `sel`:   ktab[ks*8 + c] = sel << 28 | kofs.   3x3: sel = tap 0..8, 9 = K tail (the
+  // row masks carry a permanently set bit 9); 1x1: sel = segment 0/1, tail = bit 31 of kofs.
+  // This replaces a per-step walker (divisions by 3, a divergent carry loop) with one ds_read.
+  uint32_t* const ktab = reinterpret_cast<uint32_t*>(smem + DMA_STAGES * STAGE);
+  for (int e = tid; e < a.nk * 8; e += 512) {
+    const int q = e;                       // chunk index on the flattened K axis
+    uint32_t v;
+    if constexpr (KS == 3) {
+      const int tp = q / ct0, co = q - tp * ct0;
+      v = (tp < 9) ? ((uint32_t)tp << 28) | (uint32_t)((((tp / 3) * a.src[0].w + tp % 3) * a.src[0].ld + co * CE) * (int)sizeof(T))
+                   : (9u << 28);
+    } else {
+      const bool s1 = q >= ct0;
+      const int cq = s1 ? q - ct0 : q;
+      const bool ok = cq < (s1 ? ct1 : ct0);
+      v = ok ? ((s1 ? 1u : 0u) << 28) | (uint32_t)(cq * CE * (int)sizeof(T)) : kOob;
+    }
+    ktab[e] = v;
+  }
+  __syncthreads();
+
   // ---- DMA-side state: the tile whose stages are being issued
   int32_t xoff0[XI];
   int32_t xoff1[KS == 1 ? XI : 1];
-  uint32_t xmask[XI];
+  uint32_t xinv[XI];         // 3x3: bit t = tap t OUTSIDE the image (bit 9 always set); 1x1: 0 / 0x80000000
   uint32_t woff[NI - XI];
-  int tap = 0, coff = 0;
   int d_tile = first, d_ks = 0, d_slot = 0, d_issued = 0;
 
   auto setup_tile = [&](int tile) {      // per-lane row state of `tile` (magic divisions only)
@@ -94,13 +116,13 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
         const uint32_t hm = (hi0 >= 0 ? 1u : 0u) | 2u | ((hi0 + 2 < a.Hin) ? 4u : 0u);
         const uint32_t wm = (wi0 >= 0 ? 1u : 0u) | 2u | ((wi0 + 2 < a.Win) ? 4u : 0u);
         uint32_t msk = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
-        xmask[i] = vm ? msk : 0u;
+        xinv[i] = (vm ? (~msk & 0x1FFu) : 0x1FFu) | 0x200u;
       } else {
         const int h0 = a.src[0].up ? (ho >> 1) : ho, w0 = a.src[0].up ? (wo >> 1) : wo;
         xoff0[i] = (((b * a.src[0].h + h0) * a.src[0].w + w0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
         const int h1 = a.src[1].up ? (ho >> 1) : ho, w1 = a.src[1].up ? (wo >> 1) : wo;
         xoff1[i] = (((b * a.src[1].h + h1) * a.src[1].w + w1) * a.src[1].ld + a.src[1].ch_off) * (int)sizeof(T);
-        xmask[i] = vm ? 1u : 0u;
+        xinv[i] = vm ? 0u : kOob;
       }
     }
 #pragma unroll
@@ -108,45 +130,37 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       const int row = 8 * (wave + 8 * i) + rsub, n = n0 + row;
       woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cg * 16) : kOob;
     }
-    tap = 0; coff = cg;
-    if constexpr (KS == 3) {
-      tap = cg / ct0;
-      coff = cg - tap * ct0;
-    }
   };
 
   // issue the NI DMAs of the DMA stream's next (tile, K step); branch-free validity (conv_dma.h)
+  // timing experiments (a.ablate, results wrong): 1 = no tile DMA, 128 = activation offsets wrapped
+  // into a 1 MiB window (everything L2 resident), 256 = activation rows forced to 128-byte alignment
+  const uint32_t ab_and = (ABL(128) ? 0x800FFFFFu : 0xFFFFFFFFu) & (ABL(256) ? 0xFFFFFF8Fu : 0xFFFFFFFFu);   // all ones in the shipped build
   auto issue_next = [&]() {
     const uint32_t st = lds_base + (uint32_t)(d_slot * STAGE + wave * 1024);
     const int ks = d_ks;
+    if (!ABL(1)) {
+    const uint32_t e = ktab[ks * 8 + cg];
     if constexpr (KS == 3) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int32_t toff = ((ky * a.src[0].w + kx) * a.src[0].ld + coff * CE) * (int)sizeof(T);
+      const uint32_t tp = e >> 28, kofs = e & 0x0FFFFFFFu;
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
-        const uint32_t bit = (xmask[i] >> tap) & 1u;
-        const uint32_t off = (uint32_t)(xoff0[i] + toff) | ((bit ^ 1u) << 31);
+        const uint32_t off = (((uint32_t)xoff0[i] + kofs) | (((xinv[i] >> tp) & 1u) << 31)) & ab_and;
         lds_dma16(rs0, st + i * 8192, off);
       }
-      coff += 8;
-      while (coff >= ct0) { coff -= ct0; ++tap; }
     } else {
-      const int q = ks * 8 + cg;
-      const bool seg1 = (ks * 8) >= ct0;
-      const int cq = seg1 ? q - ct0 : q;
-      const int lim = seg1 ? ct1 : ct0;
-      const uint32_t kvb = ((uint32_t)(cq - lim)) >> 31;
-      const int32_t toff = cq * CE * (int)sizeof(T);
+      const bool seg1 = (ks * 8) >= ct0;                      // wave-uniform (segment 0 is K-step aligned)
+      const uint32_t kofs = e & 0x8FFFFFFFu;                  // bit 31 = K tail
       if (!seg1) {
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-          const uint32_t off = (uint32_t)(xoff0[i] + toff) | (((kvb & xmask[i]) ^ 1u) << 31);
+          const uint32_t off = (((uint32_t)xoff0[i] + kofs) | xinv[i]) & ab_and;
           lds_dma16(rs0, st + i * 8192, off);
         }
       } else {
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-          const uint32_t off = (uint32_t)(xoff1[i] + toff) | (((kvb & xmask[i]) ^ 1u) << 31);
+          const uint32_t off = (((uint32_t)xoff1[i] + kofs) | xinv[i]) & ab_and;
           lds_dma16(rs1, st + i * 8192, off);
         }
       }
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       const uint32_t off = woff[i] + (uint32_t)(ks * 128);
       lds_dma16(rsw, st + BM * ROW_BYTES + i * 8192, off);
     }
+    }   // !(ablate & 1)
     d_slot = (d_slot == 2) ? 0 : d_slot + 1;
     ++d_issued;
     if (++d_ks == a.nk) {                 // DMA stream moves on to this workgroup's next tile
@@ -184,10 +199,17 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j)
         bf[j] = *reinterpret_cast<const uint4*>(xs + lds_off((wp * TPW + j) * 16 + frow, kk * 4 + fq));
+      if (!ABL(2)) {
 #pragma unroll
-      for (int i = 0; i < TC; ++i)
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TPW; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) acc[i][j][0] += __uint_as_float(af[i].x ^ bf[j].y);
+      }
     }
   };
 
@@ -197,15 +219,30 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   if (total_steps > 1) issue_next();
 
   int c_tile = first, c_ks = 0, c_slot = 0;
+#if MIYOLO_ABLATE
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, acc_epi = 0, t_begin = 0;
+  STAMP(t_begin);
+#endif
   for (int c = 0; c < total_steps; ++c) {
+    STAMP(t0);
     if (c + 1 < total_steps) {
       if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    STAMP(t1);
+    // (Tried and rejected, profiles/r01_conv_stamps.md: letting waves 4-7 run MFMAs first and DMAs
+    // second, so that the vector-memory path and the matrix pipe overlap across SIMD partners,
+    // made every layer 20-25 % slower - the LDS-DMA writes and the partner's ds_reads/MFMA issue
+    // interfere.)
     if (d_issued < total_steps) issue_next();
+    STAMP(t2);
     compute(c_slot);
+    STAMP(t3);
+#if MIYOLO_ABLATE
+    acc_wait += t1 - t0; acc_issue += t2 - t1; acc_comp += t3 - t2;
+#endif
     c_slot = (c_slot == 2) ? 0 : c_slot + 1;
     if (++c_ks == a.nk) {
       // ---- epilogue of tile c_tile (the next tile's first stages are already in flight)
@@ -239,13 +276,25 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
             v[r] = x;
             acc[i][j][r] = 0.f;
           }
-          if (n < a.cout && m < a.M) epilogue_store<T>(a, m, n, v);
+          if (n < a.cout && m < a.M && (!ABL(8) || v[0] == 123.456f)) epilogue_store<T>(a, m, n, v);
         }
       }
       c_ks = 0;
       c_tile += G;
+      STAMP(t4);
+#if MIYOLO_ABLATE
+      acc_epi += t4 - t3;
+#endif
     }
   }
+#if MIYOLO_ABLATE
+  if (a.dbg && lane == 0) {          // per wave: total, wait, issue, compute, epilogue cycles + steps
+    STAMP(t4);
+    unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    d[0] = t4 - t_begin; d[1] = acc_wait; d[2] = acc_issue; d[3] = acc_comp; d[4] = acc_epi; d[5] = (unsigned long long)total_steps;
+    d[6] = (unsigned long long)my_tiles; d[7] = 1;
+  }
+#endif
 }
 
 // host: magic constants for floor(x/d), x < 2^31 (Granlund-Montgomery, 31-bit dividend):
@@ -262,7 +311,8 @@ inline void host_magic(uint32_t d, uint32_t* mul, uint32_t* shift) {
 template <typename T, int KS, int WC, int TC>
 inline hipError_t launch_dmap_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
   constexpr int BN = WC * TC * 16;
-  const size_t lds = dma_lds_bytes<WC, TC>();
+  const size_t lds = dma_lds_bytes<WC, TC>() + (size_t)a.nk * 32;     // ring + K table
+  if (lds > 160 * 1024) return hipErrorInvalidValue;                  // K > ~32k: not a YOLO layer
   const long mbk = ((long)a.M + DMA_BM - 1) / DMA_BM, nb = (a.cout + BN - 1) / BN;
   long grid = std::min<long>(mbk * nb, ncu);
   grid = (grid + 7) / 8 * 8;             // the tile dealing assumes a multiple of 8

@@ -48,6 +48,8 @@ struct miyolo_engine {
                             // 3x3 s1 (conv_halo.h); 3: persistent LDS-DMA ring (conv_dmap.h)
   int ncu = 256;
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
+  unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
+  int dbg_op = -1;          // op index whose stamps are wanted
   int profile = 0;          // 1: bracket every op launch with hipEvents (bench/roofline only)
   struct ProfRec { int op, cfg; hipEvent_t e0, e1; };
   std::vector<ProfRec> prof;
@@ -118,7 +120,7 @@ hipError_t set_dmap_attrs_ks() {
   hipError_t e;
 #define MIYOLO_DMAP_ATTR(WC, TC)                                                                        \
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dmap_kernel<T, KS, WC, TC>),         \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes<WC, TC>())) != hipSuccess) return e;
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
   MIYOLO_DMAP_ATTR(1, 2) MIYOLO_DMAP_ATTR(1, 1)
 #undef MIYOLO_DMAP_ATTR
@@ -277,6 +279,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.vec_ok = (op.cout % 4 == 0) && (ob.channels % 4 == 0) && (op.dst.ch_off % 4 == 0);
       a.exact = (h->desc.dtype == MIYOLO_F32);
       a.ablate = h->ablate;
+      a.dbg = (h->dbg && (&op - h->ops.data()) == h->dbg_op) ? h->dbg : nullptr;
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
@@ -475,6 +478,12 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "profile")) { h->profile = value; return 0; }
   if (!strcmp(key, "conv_impl")) { h->conv_impl = value; return 0; }
   if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }
+  if (!strcmp(key, "dbg_op")) {
+    h->dbg_op = value;
+    if (!h->dbg) { if (hipMalloc(reinterpret_cast<void**>(&h->dbg), 256 * 8 * 8 * 8) != hipSuccess) return fail(h, MIYOLO_ERR_HIP, "hipMalloc dbg"); }
+    (void)hipMemset(h->dbg, 0, 256 * 8 * 8 * 8);
+    return 0;
+  }
   return fail(h, MIYOLO_ERR_ARG, "unknown option %s", key);
 }
 
@@ -649,6 +658,14 @@ int miyolo_profile_read(miyolo_handle h, int max_records, int32_t* op_index, int
     h->prof.clear();
   }
   return n;
+}
+
+int miyolo_debug_stamps(miyolo_handle h, unsigned long long* out /* host, 256*8*8 */) {
+  if (!h || !h->dbg || !out) return MIYOLO_ERR_ARG;
+  DevGuard guard(h->device);
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(out, h->dbg, 256 * 8 * 8 * 8, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* flops, double* bytes) {

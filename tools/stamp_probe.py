@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""In-kernel cycle stamps of the persistent conv kernel (needs `csrc/build.sh ablate`).
+usage: python tools/stamp_probe.py [op_index ...]   (yolov8m 640x640 batch 64 f16)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from manual_yolo_amd.engine import engine_from_weights  # noqa: E402
+from manual_yolo_amd.synth import synth_frames, synth_meta, synth_state_dict  # noqa: E402
+
+ops = [int(x) for x in sys.argv[1:]] or [10, 21, 71, 18, 29]
+sd, meta = synth_state_dict("detect", 64, "m", 0), synth_meta("detect", 64, "m")
+eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+frames = torch.from_numpy(synth_frames(64, 640, 640, seed=1)).cuda()
+eng.head_raw(frames); torch.cuda.synchronize()
+buf = (C.c_ulonglong * (256 * 8 * 8))()
+for op in ops:
+    eng.set_option("dbg_op", op)
+    eng.head_raw(frames); torch.cuda.synchronize()
+    rc = eng.lib.miyolo_debug_stamps(eng.h, buf)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 8).astype(np.float64)
+    ok = a[:, :, 7] > 0
+    o = eng.prog.ops[op]
+    tot, wait, iss, comp, epi, steps, tiles = (a[:, :, k][ok] for k in range(7))
+    print(f"op {op} {o.name} k{o.ksize} cin {o.cin} cout {o.cout} down {o.down_out}: waves {ok.sum()} steps/wave {steps.mean():.1f} tiles/wg {tiles.mean():.2f}")
+    print(f"   cycles per wave: total {tot.mean():.0f} | per K step: wait+barrier {wait.sum()/steps.sum():.0f}  dma issue {iss.sum()/steps.sum():.0f}  "
+          f"reads+mfma {comp.sum()/steps.sum():.0f} | epilogue per tile {epi.sum()/tiles.sum():.0f} | unaccounted {(tot-wait-iss-comp-epi).mean():.0f}")
