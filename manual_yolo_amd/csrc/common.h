@@ -55,6 +55,7 @@ struct ConvArgs {
   int32_t pad0;
   const float* bias;  // [cout]
   void* dst;
+  uint32_t dst_bytes, res_bytes;    // sizes of the destination / residual buffers (raw-buffer bounds)
   int32_t dst_ld, dst_choff, out_f32;
   const void* res;    // nullptr: none
   int32_t res_ld, res_choff;
@@ -113,6 +114,49 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, int m, int n, 
       for (int r = 0; r < 4; ++r)
         if (n + r < a.cout) dp[r] = (T)v[r];
     }
+  }
+}
+
+// Branch-free epilogue for one (16-channel tile, 16-pixel tile) pair of a wave: 4 consecutive
+// channels n..n+3 of pixel m.  Validity (m < M, n < cout) is folded into the byte offset of raw
+// buffer stores/loads (out of range = dropped / zero), so no exec-mask branch is taken per
+// element; the activation kind is fixed by the element type (f32 = parity mode: expf + IEEE
+// divide; f16 = v_exp + v_rcp).  Requires a.vec_ok (4-channel aligned views).
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef int v4ie_t __attribute__((ext_vector_type(4)));
+template <typename T, bool OUTF32>
+__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_buffer_rsrc_t& rdst,
+                                              const __amdgpu_buffer_rsrc_t& rres, int m, int n, const f32x4& acc,
+                                              const float (&bv)[4]) {
+  const bool ok = (m < a.M) && (n < a.cout);
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = acc[r] + bv[r];
+    if (a.act) x = (sizeof(T) == 4) ? silu_exact(x) : silu_fast(x);
+    v[r] = x;
+  }
+  if (a.res) {
+    const uint32_t ro = ok ? (uint32_t)((m * a.res_ld + a.res_choff + n) * (int)sizeof(T)) : 0x80000000u;
+    if constexpr (sizeof(T) == 4) {
+      const v4ie_t r = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += __int_as_float(r[k]);
+    } else {
+      const v2i_t r = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
+      const f16x4 h = *reinterpret_cast<const f16x4*>(&r);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += (float)h[k];
+    }
+  }
+  constexpr int OS = OUTF32 ? 4 : (int)sizeof(T);
+  const uint32_t so = ok ? (uint32_t)((m * a.dst_ld + a.dst_choff + n) * OS) : 0x80000000u;
+  if constexpr (OS == 4) {
+    v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
+  } else {
+    f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
   }
 }
 

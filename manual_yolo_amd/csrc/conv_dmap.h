@@ -15,6 +15,8 @@
 // Tiles are dealt so that the tiles sharing an activation tile run on one XCD in the same time
 // slot.  Exit condition: a static trip count per workgroup (no queues, no spinning).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "conv_dma.h"
 
@@ -58,6 +60,8 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   const v4i_t rs0 = make_srd(a.src[0].ptr, a.src[0].bytes);
   const v4i_t rs1 = make_srd(a.src[1].ptr, a.src[1].bytes);
   const v4i_t rsw = make_srd(a.w, a.wbytes);
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.dst), 0, a.res ? a.res_bytes : 0u, 0x00020000);
   const uint32_t lds_base = (uint32_t)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   constexpr uint32_t kOob = 0x80000000u;
 
@@ -252,31 +256,48 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       // here would make the compiler wait vmcnt(0) and drain the next tile's DMAs in flight.
       // The bias array is padded to a multiple of 128 floats by the host (weights.py).
       const float* __restrict__ bias = a.bias;
+      auto run_epilogue = [&](auto outf32_tag) {
+        constexpr bool OUTF32 = decltype(outf32_tag)::value;
 #pragma unroll
-      for (int i = 0; i < TC; ++i) {
-        const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + i) * 16);
-        const int n = nt + fq * 4;
-        v4i_t s0, s1, s2, s3;            // 16 consecutive biases of this 16-channel tile, in SGPRs
-        const float* bp = bias + nt;
-        asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
-                     "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
-        float bv[4];
+        for (int i = 0; i < TC; ++i) {
+          const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + i) * 16);
+          const int n = nt + fq * 4;
+          v4i_t s0, s1, s2, s3;            // 16 consecutive biases of this 16-channel tile, in SGPRs
+          const float* bp = bias + nt;
+          asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
+                       "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
+          float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+          for (int r = 0; r < 4; ++r)
+            bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          const int m = m0 + (wp * TPW + j) * 16 + frow;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = acc[i][j][r] + bv[r];
-            if (a.act) x = a.exact ? silu_exact(x) : silu_fast(x);
-            v[r] = x;
-            acc[i][j][r] = 0.f;
+          for (int j = 0; j < TPW; ++j) {
+            const int m = m0 + (wp * TPW + j) * 16 + frow;
+            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, rres, m, n, acc[i][j], bv);
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
-          if (n < a.cout && m < a.M && (!ABL(8) || v[0] == 123.456f)) epilogue_store<T>(a, m, n, v);
+        }
+      };
+      if (a.vec_ok) {
+        if (a.out_f32) run_epilogue(std::true_type{}); else run_epilogue(std::false_type{});
+      } else {                                   // odd channel counts (e.g. nc = 13): scalar path
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+          const int n = n0 + (wc * TC + i) * 16 + fq * 4;
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            const int m = m0 + (wp * TPW + j) * 16 + frow;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[i][j][r] + ((n + r < a.cout) ? bias[n + r] : 0.f);
+              if (a.act) x = a.exact ? silu_exact(x) : silu_fast(x);
+              v[r] = x;
+              acc[i][j][r] = 0.f;
+            }
+            if (n < a.cout && m < a.M) epilogue_store<T>(a, m, n, v);
+          }
         }
       }
       c_ks = 0;

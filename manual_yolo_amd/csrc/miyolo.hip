@@ -265,9 +265,11 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.bias = static_cast<const float*>(h->weights[op.bias]);
       a.dst = buf_ptr(h, p, op.dst.buf, in, ws);
       a.dst_ld = ob.channels; a.dst_choff = op.dst.ch_off; a.out_f32 = (ob.dtype == MIYOLO_F32);
+      a.dst_bytes = (uint32_t)((size_t)Bc * (H / ob.down) * (W / ob.down) * ob.channels * elem_size(h, ob));
       if (op.res.buf >= 0) {
         a.res = buf_ptr(h, p, op.res.buf, in, ws);
         a.res_ld = h->bufs[op.res.buf].channels; a.res_choff = op.res.ch_off;
+        a.res_bytes = (uint32_t)((size_t)Bc * (H / h->bufs[op.res.buf].down) * (W / h->bufs[op.res.buf].down) * a.res_ld * sizeof(T));
       }
       a.B = Bc; a.Hin = H / down_in; a.Win = W / down_in; a.Hout = H / ob.down; a.Wout = W / ob.down;
       if (down_in * op.stride != ob.down) return fail(h, MIYOLO_ERR_ARG, "conv resolution mismatch");
@@ -276,7 +278,8 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       const int K = op.cin * op.ksize * op.ksize, BK = 8 * CE;
       a.kpad = (K + BK - 1) / BK * BK; a.nk = a.kpad / BK;
       a.wbytes = (uint32_t)((size_t)op.cout * a.kpad * sizeof(T));
-      a.vec_ok = (op.cout % 4 == 0) && (ob.channels % 4 == 0) && (op.dst.ch_off % 4 == 0);
+      a.vec_ok = (op.cout % 4 == 0) && (ob.channels % 4 == 0) && (op.dst.ch_off % 4 == 0) &&
+                 (op.res.buf < 0 || (h->bufs[op.res.buf].channels % 4 == 0 && op.res.ch_off % 4 == 0));
       a.exact = (h->desc.dtype == MIYOLO_F32);
       a.ablate = h->ablate;
       a.dbg = (h->dbg && (&op - h->ops.data()) == h->dbg_op) ? h->dbg : nullptr;
