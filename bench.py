@@ -169,13 +169,24 @@ def main():
             e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
         dom = max(per.items(), key=lambda kv: kv[1][1])
         name, (n, ms, fl, by) = dom
+        # HBM traffic per launch of that kernel: not measurable from inside this process - taken from the
+        # committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json), same workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
+            if key in tj and (B, H, W, args.dtype, args.scale) == (64, 640, 640, "f16", "m"):
+                traffic = round(tj[key]["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
         total_ms = sum(v[1] for v in per.values())
         conv_fl = sum(v[2] for k, v in per.items() if k.startswith("conv")); conv_ms = sum(v[1] for k, v in per.items() if k.startswith("conv"))
         if fl > 0:
             ach = fl / (ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype],
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
+                        "algorithmic_bytes_per_launch": round(by / n),
                         "share_of_step_kernel_time": round(ms / total_ms, 3),
                         "all_convs_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None}
         else:

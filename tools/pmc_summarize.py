@@ -44,7 +44,7 @@ def main():
                 continue
             for row in csv.DictReader(open(f)):
                 dur[short(row["Kernel_Name"])] += (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6
-    lines = ["| kernel | launches | ms | MFMA busy % | wait_any % | wait_inst % | LDS conflict % | L2 hit % | "
+    lines = ["| kernel | launches | ms | MFMA util % | wait_any % | wait_inst % | LDS conflict % | L2 hit % | "
              "fetch GB (x2) | write GB | HBM rd GB/s | TA rd req/launch |", "|" + "---|" * 12]
     for k in sorted(data, key=lambda x: -dur.get(x, 0)):
         d = data[k]
@@ -52,8 +52,10 @@ def main():
         ms = dur.get(k, 0.0)
         busy = d.get("SQ_BUSY_CYCLES", 0)
         wc = d.get("SQ_WAVE_CYCLES", 0)
-        # SQ_WAVE_CYCLES etc. count quad-cycles per wave; MFMA_BUSY counts cycles per SIMD(?) - report raw ratios
-        mfma = 100 * d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (busy * 4) if busy else 0   # 4 SIMDs per CU... see DESIGN.md
+        # SQ_VALU_MFMA_BUSY_CYCLES sums matrix-pipe busy cycles over the 1024 SIMDs; GRBM_GUI_ACTIVE sums shader
+        # clocks over the 8 XCDs (separate pass): utilisation = busy / (1024 * GRBM/8)
+        gui = d.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        mfma = 100 * d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024.0 * gui) if gui else 0
         wa = 100 * d.get("SQ_WAIT_ANY", 0) / wc if wc else 0
         wi = 100 * d.get("SQ_WAIT_INST_ANY", 0) / wc if wc else 0
         ldsc = 100 * d.get("SQ_LDS_BANK_CONFLICT", 0) / d.get("SQ_LDS_IDX_ACTIVE", 1) if d.get("SQ_LDS_IDX_ACTIVE") else 0
