@@ -85,6 +85,8 @@ def main():
         if rank == 0:
             print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if os.environ.get("MIYOLO_FORCE_DEVICE"):          # rehearsal: several ranks on one GPU (with gloo)
+        local = int(os.environ["MIYOLO_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -26,7 +26,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MIYOLO_DIST_BACKEND=gloo lets the N>1 path be rehearsed with several ranks on ONE GPU
+            # (RCCL refuses duplicate devices); production is nccl (= RCCL over xGMI)
+            backend = os.environ.get("MIYOLO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -52,10 +54,10 @@ def all_gather_detections(dets: torch.Tensor, counts: torch.Tensor, group=None,
         gc = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
     else:
         gd, gc = out
-    if dets.is_cuda:
+    if dets.is_cuda and dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(gd, dets.contiguous(), group=group)
         dist.all_gather_into_tensor(gc, counts.contiguous(), group=group)
-    else:  # gloo
+    else:  # gloo (CPU tests, single-GPU rehearsal)
         dist.all_gather(list(gd.chunk(world)), dets.contiguous(), group=group)
         dist.all_gather(list(gc.chunk(world)), counts.contiguous(), group=group)
     return gd, gc
