@@ -22,6 +22,15 @@
 
 namespace miyolo {
 
+// Ring depth per tile shape: the 256 x 192 tile (56 KiB per stage) only fits twice; its steps are twice as
+// long (48 MFMAs per wave), which is what hides the DMA latency with one stage in flight.
+template <int WC, int TC>
+constexpr int dmap_stages() { return (WC * TC * 16 > 128) ? 2 : 3; }
+template <int WC, int TC>
+constexpr size_t dmap_lds_bytes() {
+  return (size_t)dmap_stages<WC, TC>() * (DMA_BM + (WC * TC * 16 + 63) / 64 * 64) * ROW_BYTES;
+}
+
 __device__ __forceinline__ uint32_t magic_div(uint32_t x, uint32_t mul, uint32_t shift) {
   // floor(x / d) for x < 2^31; (mul, shift) from host_magic(d); d == 1 is encoded as mul == 0
   return mul ? (__umulhi(x, mul) >> shift) : x;
@@ -39,6 +48,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   constexpr int NI = ROWS / 64;
   constexpr int XI = BM / 64;
   constexpr int STAGE = ROWS * ROW_BYTES;
+  constexpr int NST = dmap_stages<WC, TC>();   // ring slots: 3 (two steps ahead), 2 for the 192-channel tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -76,7 +86,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   // segment `sel`:   ktab[ks*8 + c] = sel << 28 | kofs.   3x3: sel = tap 0..8, 9 = K tail (the
   // row masks carry a permanently set bit 9); 1x1: sel = segment 0/1, tail = bit 31 of kofs.
   // This replaces a per-step walker (divisions by 3, a divergent carry loop) with one ds_read.
-  uint32_t* const ktab = reinterpret_cast<uint32_t*>(smem + DMA_STAGES * STAGE);
+  uint32_t* const ktab = reinterpret_cast<uint32_t*>(smem + NST * STAGE);
   for (int e = tid; e < a.nk * 8; e += 512) {
     const int q = e;                       // chunk index on the flattened K axis
     uint32_t v;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       lds_dma16(rsw, st + BM * ROW_BYTES + i * 8192, off);
     }
     }   // !(ablate & 1)
-    d_slot = (d_slot == 2) ? 0 : d_slot + 1;
+    d_slot = (d_slot == NST - 1) ? 0 : d_slot + 1;
     ++d_issued;
     if (++d_ks == a.nk) {                 // DMA stream moves on to this workgroup's next tile
       d_ks = 0;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   // ---- stream: prologue issues two stages, then one barrier + one issue + one compute per step
   setup_tile(d_tile);
   issue_next();
-  if (total_steps > 1) issue_next();
+  if (NST > 2 && total_steps > 1) issue_next();
 
   int c_tile = first, c_ks = 0, c_slot = 0;
 #if MIYOLO_ABLATE
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #endif
   for (int c = 0; c < total_steps; ++c) {
     STAMP(t0);
-    if (c + 1 < total_steps) {
+    if (NST > 2 && c + 1 < total_steps) {      // one younger stage may stay in flight
       if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     } else {
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #if MIYOLO_ABLATE
     acc_wait += t1 - t0; acc_issue += t2 - t1; acc_comp += t3 - t2;
 #endif
-    c_slot = (c_slot == 2) ? 0 : c_slot + 1;
+    c_slot = (c_slot == NST - 1) ? 0 : c_slot + 1;
     if (++c_ks == a.nk) {
       // ---- epilogue of tile c_tile (the next tile's first stages are already in flight)
       const int mb = c_tile / NB, nb = c_tile - mb * NB;
@@ -332,7 +342,7 @@ inline void host_magic(uint32_t d, uint32_t* mul, uint32_t* shift) {
 template <typename T, int KS, int WC, int TC>
 inline hipError_t launch_dmap_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
   constexpr int BN = WC * TC * 16;
-  const size_t lds = dma_lds_bytes<WC, TC>() + (size_t)a.nk * 32;     // ring + K table
+  const size_t lds = dmap_lds_bytes<WC, TC>() + (size_t)a.nk * 32;    // ring + K table
   if (lds > 160 * 1024) return hipErrorInvalidValue;                  // K > ~32k: not a YOLO layer
   const long mbk = ((long)a.M + DMA_BM - 1) / DMA_BM, nb = (a.cout + BN - 1) / BN;
   long grid = std::min<long>(mbk * nb, ncu);
@@ -343,6 +353,7 @@ inline hipError_t launch_dmap_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
 
 template <typename T, int KS>
 inline hipError_t launch_dmap_ks(const ConvArgs& a, ConvCfg c, hipStream_t s, int ncu) {
+  if (c.wc == 2 && c.tc == 6) return launch_dmap_cfg<T, KS, 2, 6>(a, s, ncu);
   if (c.wc == 2 && c.tc == 4) return launch_dmap_cfg<T, KS, 2, 4>(a, s, ncu);
   if (c.wc == 2 && c.tc == 3) return launch_dmap_cfg<T, KS, 2, 3>(a, s, ncu);
   if (c.wc == 1 && c.tc == 4) return launch_dmap_cfg<T, KS, 1, 4>(a, s, ncu);
@@ -351,9 +362,20 @@ inline hipError_t launch_dmap_ks(const ConvArgs& a, ConvCfg c, hipStream_t s, in
   return launch_dmap_cfg<T, KS, 1, 1>(a, s, ncu);
 }
 
+// Tile choice for the persistent kernel: as pick_dma_cfg, plus the 256 x 192 tile (8 waves of 64 x 96:
+// 30 % fewer LDS fragment bytes and 37 % fewer filled bytes per FLOP than 64 x 48 wave tiles) for layers with
+// exactly 192 output channels and at least one tile per CU.  Measured (profiles/r01_tile_256x192.md): +12...16 %
+// on those layers (the activation tile is fetched once instead of twice), but -8...-13 % on the 384/576-channel
+// layers, where it halves the tile count (coarser tail) and runs on a 2-slot ring - so not used there.
+inline ConvCfg pick_dmap_cfg(int cout, long M, int ncu) {
+  const long mbk = (M + DMA_BM - 1) / DMA_BM;
+  if (cout == 192 && mbk >= ncu) return {2, 6};
+  return pick_dma_cfg(cout, M);
+}
+
 template <typename T>
 inline hipError_t launch_conv_dmap(const ConvArgs& a, hipStream_t s, int ncu, int force_wc = 0, int force_tc = 0) {
-  ConvCfg c = pick_dma_cfg(a.cout, a.M);
+  ConvCfg c = pick_dmap_cfg(a.cout, a.M, ncu);
   if (force_wc > 0 && force_tc > 0) c = {force_wc, force_tc};
   if (a.ksize == 3) return launch_dmap_ks<T, 3>(a, c, s, ncu);
   return launch_dmap_ks<T, 1>(a, c, s, ncu);

@@ -121,7 +121,7 @@ hipError_t set_dmap_attrs_ks() {
 #define MIYOLO_DMAP_ATTR(WC, TC)                                                                        \
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dmap_kernel<T, KS, WC, TC>),         \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
+  MIYOLO_DMAP_ATTR(2, 6) MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
   MIYOLO_DMAP_ATTR(1, 2) MIYOLO_DMAP_ATTR(1, 1)
 #undef MIYOLO_DMAP_ATTR
   return hipSuccess;
@@ -351,7 +351,8 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
                     halo_xi(p.W / ob.down) <= 8;
   const int impl = h->conv_impl == 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
-  ConvCfg c = impl == 2 ? pick_halo_cfg(op.cout, M) : impl >= 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
+  ConvCfg c = impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
+              : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
   if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
   return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 2323 = conv_halo_kernel<T,2,3>
 }

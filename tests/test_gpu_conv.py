@@ -136,3 +136,17 @@ def test_halo_kernel_shapes(dtype, cin, cout, H, W, B, force):
     res = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype)
     y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, res, B, H, W, force=force, impl=2)
     assert rel_err(y, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cin,cout,k,s,H,W,B", [(192, 192, 3, 1, 40, 40, 2), (384, 384, 1, 1, 24, 24, 1),
+                                               (96, 192, 3, 2, 32, 32, 2), (64, 200, 3, 1, 12, 20, 3)])
+def test_wide_tile_256x192(dtype, cin, cout, k, s, H, W, B):
+    """conv_dmap.h <WC=2,TC=6>: 256 px x 192 ch tile on a 2-slot ring (forced; also with a channel tail)."""
+    rng = np.random.default_rng(cin + cout)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = q(rng.standard_normal((B, H // s, W // s, cout)).astype(np.float32), dtype)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, res, B, H, W, force=(2, 6), impl=3)
+    assert rel_err(y, ref_conv(x, w, b, s, True, res)) < TOL[dtype]
