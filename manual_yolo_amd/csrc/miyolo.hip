@@ -18,6 +18,7 @@
 #include "conv_dma.h"
 #include "conv_halo.h"
 #include "conv_dmap.h"
+#include "conv_halop.h"
 #include "kernels_misc.h"
 #include "nms.h"
 
@@ -124,6 +125,18 @@ hipError_t set_dmap_attrs_ks() {
   MIYOLO_DMAP_ATTR(2, 6) MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
   MIYOLO_DMAP_ATTR(1, 2) MIYOLO_DMAP_ATTR(1, 1)
 #undef MIYOLO_DMAP_ATTR
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t set_halop_attrs() {
+  hipError_t e;
+#define MIYOLO_HALOP_ATTR(WC, TC)                                                                      \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halop_kernel<T, WC, TC>),           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  MIYOLO_HALOP_ATTR(2, 4) MIYOLO_HALOP_ATTR(2, 3) MIYOLO_HALOP_ATTR(1, 4) MIYOLO_HALOP_ATTR(1, 3)
+  MIYOLO_HALOP_ATTR(1, 2) MIYOLO_HALOP_ATTR(1, 1)
+#undef MIYOLO_HALOP_ATTR
   return hipSuccess;
 }
 
@@ -286,7 +299,8 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
-      if (h->conv_impl == 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      if (h->conv_impl == 4 && halop_eligible(a)) HIP_TRY(h, launch_conv_halop<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
       else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
       else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
@@ -350,8 +364,10 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   const long M = (long)p.B * (p.H / ob.down) * (p.W / ob.down);
   const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
                     halo_xi(p.W / ob.down) <= 8;
-  const int impl = h->conv_impl == 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
-  ConvCfg c = impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
+  const bool halop = h->conv_impl == 4 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
+                     (p.W / ob.down) <= 95 && op.cout % 4 == 0;
+  const int impl = halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
+  ConvCfg c = impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
               : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
   if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
   return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 2323 = conv_halo_kernel<T,2,3>
@@ -457,6 +473,8 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_dmap_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_halop_attrs<float>();
+  if (e == hipSuccess) e = set_halop_attrs<half_t>();
   if (e == hipSuccess) e = set_halo_attrs<float>();
   if (e == hipSuccess) e = set_halo_attrs<half_t>();
   if (e == hipSuccess)

@@ -21,7 +21,7 @@ def ref_conv(x, w, b, s, act, res=None):
     return y + res if res is not None else y
 
 
-IMPLS = [0, 1, 2, 3]   # 3: persistent LDS-DMA ring (conv_dmap.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+IMPLS = [0, 1, 2, 3, 4]   # 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -126,15 +126,20 @@ def test_head_final_conv_f32_out(dtype, cout, impl):
     (64, 64, 40, 40, 1, (1, 4)),
     (288, 96, 6, 10, 5, (2, 3)),
     (32, 16, 4, 4, 70, (1, 1)),       # many tiny frames per tile
+    (96, 96, 80, 80, 2, None),        # the 80x80 level: halo buffer at its 448-row / 160 KiB limit
+    (288, 288, 20, 20, 4, None),      # 4.5 chunks: trailing 32-channel chunk
+    (80, 64, 24, 94, 1, (1, 4)),      # widest map the persistent halo kernel takes, 1.25 chunks
 ])
-def test_halo_kernel_shapes(dtype, cin, cout, H, W, B, force):
-    """conv_halo.h: shifted LDS windows, zero-row masking at frame borders, halo pieces."""
+@pytest.mark.parametrize("impl", [2, 4])
+def test_halo_kernel_shapes(dtype, cin, cout, H, W, B, force, impl):
+    """conv_halo.h / conv_halop.h: shifted LDS windows, zero-row masking at frame borders, halo pieces
+    (shapes the persistent variant does not take - width > 95 - fall back to the ring kernel)."""
     rng = np.random.default_rng(cin + cout + W)
     x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
     w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
     res = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype)
-    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, res, B, H, W, force=force, impl=2)
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, res, B, H, W, force=force, impl=impl)
     assert rel_err(y, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
 
 
