@@ -21,7 +21,7 @@ def ref_conv(x, w, b, s, act, res=None):
     return y + res if res is not None else y
 
 
-IMPLS = [0, 1, 2, 3, 4]   # 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+IMPLS = [0, 1, 2, 3, 4, 5]   # 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -155,3 +155,16 @@ def test_wide_tile_256x192(dtype, cin, cout, k, s, H, W, B):
     res = q(rng.standard_normal((B, H // s, W // s, cout)).astype(np.float32), dtype)
     y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, res, B, H, W, force=(2, 6), impl=3)
     assert rel_err(y, ref_conv(x, w, b, s, True, res)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("k,s,cin,cout,H,W,B,res", [(3, 1, 96, 64, 40, 40, 2, True), (1, 1, 192, 80, 24, 20, 3, False), (3, 2, 48, 64, 36, 28, 2, False)])
+def test_ws_2x2_consumer_grid(dtype, k, s, cin, cout, H, W, B, res):
+    """conv_ws.h's 2 x 2 consumer grid with 32-channel wave tiles (the {2,2} shape only that kernel has)."""
+    rng = np.random.default_rng(11)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H // s, W // s, cout)).astype(np.float32), dtype) if res else None
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, r, B, H, W, force=(2, 2), impl=5)
+    assert rel_err(y, ref_conv(x, w, b, s, True, r)) < TOL[dtype]
