@@ -184,7 +184,8 @@ int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int 
  * only counts, passing arrays consumes the records.  Not for the hot path. */
 int miyolo_profile_read(miyolo_handle h, int max_records, int32_t* op_index, int32_t* cfg, float* ms);
 /* Timing-experiment builds only (-DMIYOLO_ABLATE=1, option "dbg_op"): per-wave cycle stamps of the
- * persistent conv kernel for one op; `out` is a HOST buffer of 256*8*8 uint64. Synchronises. */
+ * persistent conv kernels for one op; `out` is a HOST buffer of 2*256*8*8 uint64 (second half: event trace of
+ * workgroup 0, conv_ws.h). Synchronises. */
 int miyolo_debug_stamps(miyolo_handle h, unsigned long long* out);
 /* Algorithmic flops (2*MAC) and compulsory bytes of ONE op for a B x H x W batch. */
 int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* flops, double* bytes);

@@ -4,11 +4,12 @@
 #include <stdint.h>
 
 // Timing-experiment switches (profiles/r01_conv_dma_ablation.md) are compiled in only with
-// -DMIYOLO_ABLATE=1 (csrc/build.sh ablate); the shipped kernels carry none of their branches.
+// -DMIYOLO_ABLATE=1 (csrc/build.sh ablate); -DMIYOLO_ABLATE=2 (csrc/build.sh stamps) compiles the in-kernel
+// cycle stamps only (the ablation branches change register allocation); the shipped kernels carry neither.
 #ifndef MIYOLO_ABLATE
 #define MIYOLO_ABLATE 0
 #endif
-#define ABL(bit) (MIYOLO_ABLATE && (a.ablate & (bit)))
+#define ABL(bit) (MIYOLO_ABLATE == 1 && (a.ablate & (bit)))
 #if MIYOLO_ABLATE
 #define STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
 #else

@@ -1,19 +1,21 @@
 // Implicit-GEMM convolution, warp-specialised: 4 producer waves feed an LDS ring by LDS-DMA, 4 consumer
-// waves (one per SIMD) run the MFMAs.  Persistent workgroups, same tile math / ring / K table as conv_dmap.h.
+// waves (one per SIMD) run the MFMAs.  Persistent workgroups, same tile math and K table as conv_dmap.h.
 //
-// Why (profiles/r01_conv_stamps.md, r01_halop_vs_dmap.md): when every wave both fetches and computes, a K step is
+// Why (profiles/r01_conv_stamps.md, r01_ws_kernel.md): when every wave both fetches and computes, a K step is
 // [all waves stalled in DMA issue ~900 cycles] + [both SIMD partners queueing on the matrix pipe ~770] +
-// [barrier skew ~500]: the vector-memory path, the LDS and the matrix pipe take turns instead of overlapping,
-// and MFMA utilisation stalls at ~0.25.  LDS-DMA issue blocks the issuing WAVE, not the CU - so the stall is
-// moved onto waves that have nothing else to do:
-//   * waves 4-7 (producers): per step issue the next stage's DMAs (a quarter each), wait for their part of
-//     the stage after next, barrier.  They hold ~30 VGPRs of state and never touch the matrix pipe.
-//   * waves 0-3 (consumers, one per SIMD): per step read fragments, run the MFMAs of a 128 x (48|64) or
-//     64 x (16..64) wave tile (2x the register reuse of the 64 x 48 tiles: 25-35 % fewer LDS fragment bytes per
-//     FLOP), barrier; at the end of a tile, the epilogue - during which the producers keep the ring filling.
-//   vmcnt is per wave: the consumers' epilogue loads/stores no longer share a counter with the DMAs.
-// One s_barrier per K step for all eight waves; stage c+1 is complete at the barrier that ends step c because each
-// producer waits for its own quarter before arriving.
+// [barrier skew ~500]: the vector-memory path, the LDS and the matrix pipe take turns instead of overlapping.
+// LDS-DMA issue blocks the issuing WAVE, not the CU - so the stall is moved onto waves with nothing else to do:
+//   * waves 4-7 (producers) run the fill stream: wait for a free ring slot, issue its DMAs (a quarter of the
+//     rows each), and publish a slot once their quarter has landed (vmcnt is per wave and counts in order).
+//   * waves 0-3 (consumers, one per SIMD) own a 128 x (32..64) or 64 x (16..64) channel-by-pixel wave tile (twice
+//     the register reuse of the ring kernel's 64 x 48 tiles), with a ROLLING fragment prefetch: as soon as pixel
+//     fragment j of the current stage has fed its MFMAs, its registers are reloaded from the next stage; the
+//     weight fragments are double-buffered.  One wave per SIMD then keeps the matrix pipe fed without a partner.
+// Ring: 6 slots of K = 32 elements (64-byte rows, chunk position XOR-swizzled by the row's quad within its 16-row
+// block: conflict-free ds_read_b128, and a 16-row DMA is one contiguous KiB).  Half-size stages and twice the slots, because what limits a flag-synchronised
+// ring is the loop  release slot -> poll -> issue -> land -> publish -> poll : it has (slots - 1.5) stage times to
+// complete, which 3 slots of K = 64 did not give it (measured: both sides waiting on each other).
+// Synchronisation is per slot through LDS counters (full[6], empty[6]), no s_barrier in the main loop.
 #pragma once
 #include <type_traits>
 
@@ -22,10 +24,39 @@
 
 namespace miyolo {
 
+constexpr int WS_NST = 6;          // ring slots
+constexpr int WS_ROW = 64;         // bytes per LDS row of a stage (4 chunks of 16 B = 32 f16 / 16 f32 of K)
 template <int CN, int TC>
-constexpr int ws_bnp() { return (CN * TC * 16 + 31) / 32 * 32; }
+constexpr int ws_bnp() { return (CN * TC * 16 + 63) / 64 * 64; }
 template <int CN, int TC>
-constexpr size_t ws_lds_bytes() { return (size_t)3 * (DMA_BM + ws_bnp<CN, TC>()) * ROW_BYTES; }
+constexpr size_t ws_lds_bytes() { return (size_t)WS_NST * (DMA_BM + ws_bnp<CN, TC>()) * WS_ROW; }
+
+// LDS flag words behind the K table: full[slot] counts producer waves that have landed their quarter of the
+// stage in `slot` (4 per use of the slot), empty[slot] counts consumer waves done with it (4 per use).
+// A waiting wave polls with s_sleep; the trip counts are static, every flag is eventually raised, and a
+// bounded spin (kSpinMax polls) turns a protocol bug into wrong results instead of a hung GPU.
+// Flags are read/written with inline-asm LDS ops on raw LDS addresses: a C++ volatile/atomic access makes the
+// compiler wait vmcnt(0) first, which would drain the producers' DMAs in flight on every poll.
+constexpr int kSpinMax = 1 << 16;
+__device__ __forceinline__ uint32_t ws_peek(uint32_t flag_addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void ws_wait_ge(uint32_t flag_addr, uint32_t target) {
+#ifdef MIYOLO_WS_NOWAIT
+  return;                                // timing experiment (results wrong): no handshake at all
+#endif
+  uint32_t v = ws_peek(flag_addr);
+  int spins = 0;
+  while ((uint32_t)__builtin_amdgcn_readfirstlane((int)v) < target && ++spins < kSpinMax) {
+    __builtin_amdgcn_s_sleep(1);
+    v = ws_peek(flag_addr);
+  }
+}
+__device__ __forceinline__ void ws_signal(uint32_t flag_addr, int lane) {
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(flag_addr), "v"(1u) : "memory");
+}
 
 template <typename T, int KS, int CN, int TC>
 __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
@@ -36,11 +67,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   constexpr int BN = CN * TC * 16;
   constexpr int BNP = ws_bnp<CN, TC>();
   constexpr int ROWS = BM + BNP;
-  constexpr int XIP = BM / 32;                  // activation DMAs per producer wave per stage (8)
-  constexpr int WIP = BNP / 32;                 // weight DMAs per producer wave per stage (1..4)
+  constexpr int XIP = BM / 64;                  // activation DMAs (16 rows each) per producer wave per stage: 4
+  constexpr int WIP = BNP / 64;                 // weight DMAs per producer wave per stage: 1 or 2
   constexpr int NIP = XIP + WIP;
-  constexpr int STAGE = ROWS * ROW_BYTES;
-  constexpr int NST = 3;
+  constexpr int STAGE = ROWS * WS_ROW;
+  constexpr int NST = WS_NST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,13 +84,15 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   const int first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int my_tiles = (first < ntiles) ? (ntiles - first + G - 1) / G : 0;
   if (my_tiles == 0) return;
-  const int total_steps = my_tiles * a.nk;
+  const int nk2 = a.nk * 2;                     // stages per tile (a.nk counts K steps of 8 chunks)
+  const int total_stages = my_tiles * nk2;
   constexpr uint32_t kOob = 0x80000000u;
   const int ct0 = a.src[0].ch_cnt / CE;
   const int ct1 = (a.nsrc > 1) ? a.src[1].ch_cnt / CE : 0;
 
-  // ---- K table (see conv_dmap.h), built by all eight waves
+  // ---- K table (see conv_dmap.h: one entry per 16-byte chunk of the flattened K axis), flags zeroed
   uint32_t* const ktab = reinterpret_cast<uint32_t*>(smem + NST * STAGE);
+  uint32_t* const flags = ktab + a.nk * 8;      // full[0..5], empty[0..5]
   for (int e = tid; e < a.nk * 8; e += 512) {
     uint32_t v;
     if constexpr (KS == 3) {
@@ -74,30 +107,41 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
     }
     ktab[e] = v;
   }
+  if (tid < 2 * NST) flags[tid] = 0u;
   __syncthreads();
+  const uint32_t lds_base = (uint32_t)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t fl_full = lds_base + (uint32_t)(NST * STAGE + a.nk * 32);
+  const uint32_t fl_empty = fl_full + NST * 4;
 
   if (wave >= 4) {
     // =========================================================================== producers
     const int p = wave - 4;
+    __builtin_amdgcn_s_setprio(3);       // the few VALU ops of the fill stream go ahead of the consumer's MFMA queue
     const v4i_t rs0 = make_srd(a.src[0].ptr, a.src[0].bytes);
     const v4i_t rs1 = make_srd(a.src[1].ptr, a.src[1].bytes);
     const v4i_t rsw = make_srd(a.w, a.wbytes);
-    const uint32_t lds_base = (uint32_t)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int rsub = lane >> 3;
-    const int cg = (lane & 7) ^ (((lane >> 4) + 4 * (p & 1)) & 7);
+    const int rsub = lane >> 2;          // row within a 16-row DMA
+    // chunk swizzle: row r of a 16-row block stores logical chunk c at position c ^ ((-(r >> 2)) & 3), which puts the
+    // four 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS) on 16 distinct 16-byte bank slots
+    const int cq = (lane & 3) ^ ((4 - (lane >> 4)) & 3);   // logical K chunk this lane fetches
     const int HWo = a.Hout * a.Wout;
     int32_t xoff0[XIP];
     int32_t xoff1[KS == 1 ? XIP : 1];
     uint32_t xinv[XIP];
     uint32_t woff[WIP];
-    int d_tile = first, d_ks = 0, d_slot = 0, d_issued = 0;
+    int d_tile = first, d_ks = 0, d_slot = 0;
 
+    // Row state of a tile.  DMA i of this wave covers rows 16*(p + 4*i) + (lane >> 2): the 4 lanes of a row group
+    // share a row, so lane L computes ONE row - (i = L >> 4, row = L & 15) - and the wave transposes with
+    // ds_bpermute: DMA i of lane L takes its values from lane 16*i + (L >> 2).
+    const int bp_base = (lane >> 2) * 4;
     auto setup_tile = [&](int tile) {
       const int mb = tile / NB, nb = tile - mb * NB;
       const int m0 = mb * BM, n0 = nb * BN;
-#pragma unroll
-      for (int i = 0; i < XIP; ++i) {
-        const int m = m0 + 8 * (p + 4 * i) + rsub;
+      int32_t c_off0, c_off1 = 0;
+      uint32_t c_inv;
+      {
+        const int m = m0 + 16 * (p + 4 * (lane >> 4)) + (lane & 15);
         const bool vm = m < a.M;
         const uint32_t mm = vm ? (uint32_t)m : 0u;
         const int b = (int)magic_div(mm, a.mg_hw_mul, a.mg_hw_shift);
@@ -106,31 +150,40 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
         const int wo = (int)rem - ho * a.Wout;
         if constexpr (KS == 3) {
           const int hi0 = ho * a.stride - 1, wi0 = wo * a.stride - 1;
-          xoff0[i] = (((b * a.src[0].h + hi0) * a.src[0].w + wi0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
+          c_off0 = (((b * a.src[0].h + hi0) * a.src[0].w + wi0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
           const uint32_t hm = (hi0 >= 0 ? 1u : 0u) | 2u | ((hi0 + 2 < a.Hin) ? 4u : 0u);
           const uint32_t wm = (wi0 >= 0 ? 1u : 0u) | 2u | ((wi0 + 2 < a.Win) ? 4u : 0u);
           const uint32_t msk = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
-          xinv[i] = (vm ? (~msk & 0x1FFu) : 0x1FFu) | 0x200u;
+          c_inv = (vm ? (~msk & 0x1FFu) : 0x1FFu) | 0x200u;
         } else {
           const int h0 = a.src[0].up ? (ho >> 1) : ho, w0 = a.src[0].up ? (wo >> 1) : wo;
-          xoff0[i] = (((b * a.src[0].h + h0) * a.src[0].w + w0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
+          c_off0 = (((b * a.src[0].h + h0) * a.src[0].w + w0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
           const int h1 = a.src[1].up ? (ho >> 1) : ho, w1 = a.src[1].up ? (wo >> 1) : wo;
-          xoff1[i] = (((b * a.src[1].h + h1) * a.src[1].w + w1) * a.src[1].ld + a.src[1].ch_off) * (int)sizeof(T);
-          xinv[i] = vm ? 0u : kOob;
+          c_off1 = (((b * a.src[1].h + h1) * a.src[1].w + w1) * a.src[1].ld + a.src[1].ch_off) * (int)sizeof(T);
+          c_inv = vm ? 0u : kOob;
         }
       }
 #pragma unroll
+      for (int i = 0; i < XIP; ++i) {
+        xoff0[i] = __builtin_amdgcn_ds_bpermute(bp_base + i * 64, c_off0);
+        xinv[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + i * 64, (int)c_inv);
+        if constexpr (KS == 1) xoff1[i] = __builtin_amdgcn_ds_bpermute(bp_base + i * 64, c_off1);
+      }
+#pragma unroll
       for (int i = 0; i < WIP; ++i) {
-        const int row = 8 * (p + 4 * i) + rsub, n = n0 + row;
-        woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cg * 16) : kOob;
+        const int row = 16 * (p + 4 * i) + rsub, n = n0 + row;
+        woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cq * 16) : kOob;
       }
     };
-    const uint32_t ab_and = ABL(128) ? 0x800FFFFFu : 0xFFFFFFFFu;   // timing experiment: activations wrapped into 1 MiB (L2 resident)
-    auto issue_next = [&]() {
+#ifdef MIYOLO_WS_L2WRAP
+    const uint32_t ab_and = 0x800FFFFFu;   // timing experiment (-DMIYOLO_WS_L2WRAP, results wrong): activations wrapped into 1 MiB (L2 resident)
+#else
+    const uint32_t ab_and = ABL(128) ? 0x800FFFFFu : 0xFFFFFFFFu;
+#endif
+    auto issue_stage = [&](const uint32_t e) {   // the NIP DMAs of (d_tile, stage d_ks) into slot d_slot; e = its K-table entry
       const uint32_t st = lds_base + (uint32_t)(d_slot * STAGE + p * 1024);
       const int ks = d_ks;
       if (!ABL(1)) {                 // timing experiment (results wrong): no tile DMA
-      const uint32_t e = ktab[ks * 8 + cg];
       if constexpr (KS == 3) {
         const uint32_t tp = e >> 28, kofs = e & 0x0FFFFFFFu;
 #pragma unroll
@@ -139,7 +192,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
           lds_dma16(rs0, st + i * 4096, off);
         }
       } else {
-        const bool seg1 = (ks * 8) >= ct0;
+        const bool seg1 = (ks * 4) >= ct0;                      // wave-uniform (segment 0 is K-step aligned)
         const uint32_t kofs = e & 0x8FFFFFFFu;
         if (!seg1) {
 #pragma unroll
@@ -150,51 +203,77 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < WIP; ++i) lds_dma16(rsw, st + BM * ROW_BYTES + i * 4096, woff[i] + (uint32_t)(ks * 128));
-      }
-      d_slot = (d_slot == NST - 1) ? 0 : d_slot + 1;
-      ++d_issued;
-      if (++d_ks == a.nk) {
-        d_ks = 0;
-        d_tile += G;
-        if (d_tile < ntiles) setup_tile(d_tile);
+      for (int i = 0; i < WIP; ++i) lds_dma16(rsw, st + BM * WS_ROW + i * 4096, woff[i] + (uint32_t)(ks * 64));
       }
     };
 
-    setup_tile(d_tile);
-    issue_next();
-    if (total_steps > 1) {
-      issue_next();
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NIP) : "memory");     // stage 0 landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
 #if MIYOLO_ABLATE
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, pa_issue = 0, pa_vm = 0, pa_bar = 0, t_begin = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, pa_issue = 0, pa_vm = 0, pa_empty = 0, pa_setup = 0, t_begin = 0;
     STAMP(t_begin);
 #endif
-    for (int c = 0; c < total_steps; ++c) {
-      // during step c: issue stage c+2, then make sure this wave's quarter of stage c+1 has landed
+    setup_tile(d_tile);
+    // Up to three stages of this wave in flight: after issuing stage s the wave waits until only the two youngest
+    // are outstanding (vmcnt counts in order), i.e. stage s-2 has landed, and publishes it.
+    int n_pend = 0, pend_slot = 0;       // issued, unpublished stages: slots pend_slot, pend_slot+1, ... (mod NST)
+    uint32_t round4 = 0;                 // 4 * (uses of the current slot so far)
+    auto publish_oldest = [&]() {
+      ws_signal(fl_full + pend_slot * 4, lane);
+      pend_slot = (pend_slot == NST - 1) ? 0 : pend_slot + 1;
+      --n_pend;
+    };
+    // Flag reads cost a full LDS round trip behind whatever the wave has queued (measured ~200-400 cycles), so
+    // they are issued one stage EARLY as plain loads and only looked at when needed; the polling loop is the
+    // fallback when the early look says "not yet".
+    uint32_t pk = 0;                                            // early look at empty[d_slot]
+    uint32_t e_cur = ktab[cq];                                  // K-table entry of the stage to issue
+    for (int s = 0; s < total_stages; ++s) {
       STAMP(t0);
-      if (d_issued < total_steps) {
-        issue_next();
-        STAMP(t1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIP) : "memory");
-      } else {
-        STAMP(t1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (round4 && (uint32_t)__builtin_amdgcn_readfirstlane((int)pk) < round4)
+        ws_wait_ge(fl_empty + d_slot * 4, round4);              // slot reuse: the consumers have released stage s-6
+      STAMP(t1);
+      {
+        const int nslot = (d_slot == NST - 1) ? 0 : d_slot + 1;
+        const int nks = (d_ks + 1 == nk2) ? 0 : d_ks + 1;
+        asm volatile("" ::: "memory");
+        pk = flags[NST + nslot];
+        const uint32_t e_next = ktab[nks * 4 + cq];
+        issue_stage(e_cur);
+        e_cur = e_next;
       }
+      ++n_pend;
       STAMP(t2);
-      asm volatile("s_barrier" ::: "memory");
+      if (n_pend == 3) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIP) : "memory");
+        publish_oldest();
+      }
       STAMP(t3);
+      if (d_slot == NST - 1) { d_slot = 0; round4 += 4; } else ++d_slot;
+      if (++d_ks == nk2) {
+        d_ks = 0;
+        d_tile += G;
+        if (d_tile < ntiles) {
+          // the next tile's row state is index arithmetic on a SIMD shared with a consumer: publish what is in
+          // flight first (the consumers would otherwise wait for the tile's last stages until after the setup)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          while (n_pend > 0) publish_oldest();
+          setup_tile(d_tile);
+        }
+      }
+      STAMP(t4);
 #if MIYOLO_ABLATE
-      pa_issue += t1 - t0; pa_vm += t2 - t1; pa_bar += t3 - t2;
+      pa_empty += t1 - t0; pa_issue += t2 - t1; pa_vm += t3 - t2; pa_setup += t4 - t3;
+      if (a.dbg && blockIdx.x == 0 && p == 0 && lane == 0 && s < 480) {     // event trace of workgroup 0 (tools/stamp_probe.py --trace)
+        unsigned long long* tr = a.dbg + 16384 + (size_t)s * 8;
+        tr[0] = t0 - t_begin; tr[1] = t1 - t_begin; tr[2] = t2 - t_begin; tr[3] = t3 - t_begin; tr[4] = t4 - t_begin;
+      }
 #endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    while (n_pend > 0) publish_oldest();
 #if MIYOLO_ABLATE
-    if (a.dbg && lane == 0) {          // per producer wave: total, vmcnt wait, issue, barrier wait
+    if (a.dbg && lane == 0) {          // per producer wave: total, vmcnt wait, issue, wait for a free slot, tile setup
       unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
-      d[0] = t3 - t_begin; d[1] = pa_vm; d[2] = pa_issue; d[3] = pa_bar; d[4] = 0; d[5] = (unsigned long long)total_steps;
+      d[0] = t4 - t_begin; d[1] = pa_vm; d[2] = pa_issue; d[3] = pa_empty; d[4] = pa_setup; d[5] = (unsigned long long)(total_stages / 2);
       d[6] = (unsigned long long)my_tiles; d[7] = 2;
     }
 #endif
@@ -212,48 +291,98 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  asm volatile("s_barrier" ::: "memory");                      // prologue barrier: stage 0 is in LDS
+  // fragment addresses inside a stage: 16 rows x 64 B = one contiguous KiB per fragment
+  const uint32_t fl = (uint32_t)(frow * WS_ROW + ((fq ^ ((4 - (frow >> 2)) & 3)) * 16));
+  auto lda = [&](const unsigned char* st, int i) -> uint4 {
+    if (ABL(4)) return make_uint4(i, lane, 1, 2);          // timing experiment: no fragment reads
+    return *reinterpret_cast<const uint4*>(st + (BM + (cn * TC + i) * 16) * WS_ROW + fl);
+  };
+  auto ldb = [&](const unsigned char* st, int j) -> uint4 {
+    if (ABL(4)) return make_uint4(j, lane, 3, 4);
+    return *reinterpret_cast<const uint4*>(st + ((cm * TPW + j) * 16) * WS_ROW + fl);
+  };
+  auto mma = [&](const uint4& x, const uint4& y, f32x4& c) {
+    if (!ABL(2)) Mma<T>::run(x, y, c); else c[0] += __uint_as_float(x.x ^ y.y);
+  };
+
+  uint4 af[2][TC], bf[TPW];
   int c_tile = first, c_ks = 0, c_slot = 0;
+  uint32_t c_full = 4;                   // full[] target of the stage in c_slot
 #if MIYOLO_ABLATE
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ca_comp = 0, ca_epi = 0, ca_bar = 0, t_begin = 0;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ca_comp = 0, ca_epi = 0, ca_wait = 0, t_begin = 0;
   STAMP(t_begin);
 #endif
+  ws_wait_ge(fl_full, 4);
+#pragma unroll
+  for (int i = 0; i < TC; ++i) af[0][i] = lda(smem, i);
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) bf[j] = ldb(smem, j);
+
+  // two stages (one K step of 8 chunks) per iteration, so that the weight-fragment double buffer has static names
+  const int total_steps = total_stages >> 1;
+  uint32_t pk1 = 0;                      // early look at full[] of the next iteration's first prefetch stage
   for (int c = 0; c < total_steps; ++c) {
     STAMP(t0);
+    const int s1 = (c_slot == NST - 1) ? 0 : c_slot + 1;                 // NST is even: s1 never wraps... kept general
+    const uint32_t f1 = (c_slot == NST - 1) ? c_full + 4 : c_full;
+    const int s2 = (s1 == NST - 1) ? 0 : s1 + 1;
+    const uint32_t f2 = (s1 == NST - 1) ? f1 + 4 : f1;
+    const bool has_next = c + 1 < total_steps;
+    const bool last = (c_ks + 1 == a.nk);          // last K step of the tile: the epilogue comes before the next stage
+    // ---- even stage (fragments already in registers; every read of it is issued: the slot is free once the add runs,
+    // LDS executes a wave's ops in order).  pk1/pk2: early looks at full[s1]/full[s2] (see the producer loop).
+    ws_signal(fl_empty + c_slot * 4, lane);
+    const uint32_t pk2 = flags[s2];
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)pk1) < f1) ws_wait_ge(fl_full + s1 * 4, f1);
+    STAMP(t1);
     {
-      const unsigned char* xs = smem + c_slot * STAGE;
-      const unsigned char* ws = xs + BM * ROW_BYTES;
+      const unsigned char* sn = smem + s1 * STAGE;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint4 af[TC], bf[TPW];
-        if (!ABL(4)) {
+      for (int j = 0; j < TPW; ++j) {
 #pragma unroll
-          for (int i = 0; i < TC; ++i)
-            af[i] = *reinterpret_cast<const uint4*>(ws + lds_off((cn * TC + i) * 16 + frow, kk * 4 + fq));
+        for (int i = 0; i < TC; ++i) mma(af[0][i], bf[j], acc[i][j]);
+        bf[j] = ldb(sn, j);
+        if (j == 0) {
 #pragma unroll
-          for (int j = 0; j < TPW; ++j)
-            bf[j] = *reinterpret_cast<const uint4*>(xs + lds_off((cm * TPW + j) * 16 + frow, kk * 4 + fq));
-        } else {
-#pragma unroll
-          for (int i = 0; i < TC; ++i) af[i] = make_uint4(c + i, lane, kk, 1);
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) bf[j] = make_uint4(c + j, lane, kk, 2);
-        }
-        if (!ABL(2)) {
-#pragma unroll
-          for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) acc[i][j][0] += __uint_as_float(af[i].x ^ bf[j].y);
+          for (int i = 0; i < TC; ++i) af[1][i] = lda(sn, i);
         }
       }
     }
-    c_slot = (c_slot == NST - 1) ? 0 : c_slot + 1;
-    STAMP(t1);
+    // ---- odd stage.  On the last step of a tile the prefetch re-reads this (released) stage and the result is dropped:
+    // one code path keeps the accumulators in place; the real fragments are loaded after the epilogue.
+    STAMP(t2);
+    ws_signal(fl_empty + s1 * 4, lane);
+    pk1 = flags[(s2 == NST - 1) ? 0 : s2 + 1];                 // next iteration's s1
+    if (!last && (uint32_t)__builtin_amdgcn_readfirstlane((int)pk2) < f2) ws_wait_ge(fl_full + s2 * 4, f2);
+    STAMP(t3);
+    {
+      const unsigned char* sn = smem + (last ? s1 : s2) * STAGE;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) mma(af[1][i], bf[j], acc[i][j]);
+        bf[j] = ldb(sn, j);
+        if (j == 0) {
+#pragma unroll
+          for (int i = 0; i < TC; ++i) af[0][i] = lda(sn, i);
+        }
+      }
+    }
+    c_slot = s2;
+    c_full = f2;
+#if MIYOLO_ABLATE
+    ca_wait += (t1 - t0) + (t3 - t2); ca_comp += t2 - t1;
+    {
+      unsigned long long t5;
+      STAMP(t5);
+      if (a.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && c < 240) {
+        unsigned long long* tr = a.dbg + 16384 + 480 * 8 + (size_t)c * 8;
+        tr[0] = t0 - t_begin; tr[1] = t1 - t_begin; tr[2] = t2 - t_begin; tr[3] = t3 - t_begin; tr[4] = t5 - t_begin;
+      }
+      ca_comp += t5 - t3;
+      t3 = t5;
+    }
+#endif
     if (++c_ks == a.nk) {
       const int mb = c_tile / NB, nb = c_tile - mb * NB;
       const int m0 = mb * BM, n0 = nb * BN;
@@ -304,18 +433,29 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       }
       c_ks = 0;
       c_tile += G;
-    }
-    STAMP(t2);
-    asm volatile("s_barrier" ::: "memory");                    // end of step c: stage c+1 complete, slot c free
-    STAMP(t3);
 #if MIYOLO_ABLATE
-    ca_comp += t1 - t0; ca_epi += t2 - t1; ca_bar += t3 - t2;
+      STAMP(t0);
+      ca_epi += t0 - t3;
 #endif
+      if (has_next) {                              // first fragments of the next tile (its producers ran during the epilogue)
+        ws_wait_ge(fl_full + c_slot * 4, c_full);
+        const unsigned char* sn = smem + c_slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) af[0][i] = lda(sn, i);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) bf[j] = ldb(sn, j);
+      }
+#if MIYOLO_ABLATE
+      STAMP(t1);
+      ca_wait += t1 - t0;
+#endif
+    }
   }
 #if MIYOLO_ABLATE
-  if (a.dbg && lane == 0) {            // per consumer wave: total, barrier wait, -, compute, epilogue
+  if (a.dbg && lane == 0) {            // per consumer wave: total, wait for a full stage, -, compute, epilogue
+    STAMP(t3);
     unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
-    d[0] = t3 - t_begin; d[1] = ca_bar; d[2] = 0; d[3] = ca_comp; d[4] = ca_epi; d[5] = (unsigned long long)total_steps;
+    d[0] = t3 - t_begin; d[1] = ca_wait; d[2] = 0; d[3] = ca_comp; d[4] = ca_epi; d[5] = (unsigned long long)total_steps;
     d[6] = (unsigned long long)my_tiles; d[7] = 1;
   }
 #endif
@@ -340,7 +480,7 @@ inline ConvCfg pick_ws_cfg(int cout, long M) {
 template <typename T, int KS, int CN, int TC>
 inline hipError_t launch_ws_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
   constexpr int BN = CN * TC * 16;
-  const size_t lds = ws_lds_bytes<CN, TC>() + (size_t)a.nk * 32;
+  const size_t lds = ws_lds_bytes<CN, TC>() + (size_t)a.nk * 32 + 64;   // ring + K table + flags
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const long mbk = ((long)a.M + DMA_BM - 1) / DMA_BM, nb = (a.cout + BN - 1) / BN;
   long grid = std::min<long>(mbk * nb, ncu);

@@ -520,8 +520,8 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }
   if (!strcmp(key, "dbg_op")) {
     h->dbg_op = value;
-    if (!h->dbg) { if (hipMalloc(reinterpret_cast<void**>(&h->dbg), 256 * 8 * 8 * 8) != hipSuccess) return fail(h, MIYOLO_ERR_HIP, "hipMalloc dbg"); }
-    (void)hipMemset(h->dbg, 0, 256 * 8 * 8 * 8);
+    if (!h->dbg) { if (hipMalloc(reinterpret_cast<void**>(&h->dbg), 2 * 256 * 8 * 8 * 8) != hipSuccess) return fail(h, MIYOLO_ERR_HIP, "hipMalloc dbg"); }
+    (void)hipMemset(h->dbg, 0, 2 * 256 * 8 * 8 * 8);
     return 0;
   }
   return fail(h, MIYOLO_ERR_ARG, "unknown option %s", key);
@@ -704,7 +704,7 @@ int miyolo_debug_stamps(miyolo_handle h, unsigned long long* out /* host, 256*8*
   if (!h || !h->dbg || !out) return MIYOLO_ERR_ARG;
   DevGuard guard(h->device);
   HIP_TRY(h, hipDeviceSynchronize());
-  HIP_TRY(h, hipMemcpy(out, h->dbg, 256 * 8 * 8 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(out, h->dbg, 2 * 256 * 8 * 8 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
