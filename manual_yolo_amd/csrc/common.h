@@ -125,10 +125,24 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, int m, int n, 
 // divide; f16 = v_exp + v_rcp).  Requires a.vec_ok (4-channel aligned views).
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 typedef int v4ie_t __attribute__((ext_vector_type(4)));
+// The residual operand of one (m, n..n+3) group, loaded ahead of use: callers issue the loads of a whole row of
+// pixel tiles first and then run the activations, so the loads' latency is paid once per row instead of once per
+// 16x16 tile (the compiler waits vmcnt(0) at the first use).  f16: components 0-1 hold the 4 halves.
+template <typename T>
+__device__ __forceinline__ v4ie_t epilogue_res_load(const ConvArgs& a, const __amdgpu_buffer_rsrc_t& rres, int m, int n) {
+  const bool ok = (m < a.M) && (n < a.cout);
+  const uint32_t ro = ok ? (uint32_t)((m * a.res_ld + a.res_choff + n) * (int)sizeof(T)) : 0x80000000u;
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+  } else {
+    const v2i_t r = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
+    return (v4ie_t){r[0], r[1], 0, 0};
+  }
+}
+
 template <typename T, bool OUTF32>
-__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_buffer_rsrc_t& rdst,
-                                              const __amdgpu_buffer_rsrc_t& rres, int m, int n, const f32x4& acc,
-                                              const float (&bv)[4]) {
+__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_buffer_rsrc_t& rdst, int m, int n,
+                                              const f32x4& acc, const float (&bv)[4], const v4ie_t& res) {
   const bool ok = (m < a.M) && (n < a.cout);
   float v[4];
 #pragma unroll
@@ -138,14 +152,12 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_
     v[r] = x;
   }
   if (a.res) {
-    const uint32_t ro = ok ? (uint32_t)((m * a.res_ld + a.res_choff + n) * (int)sizeof(T)) : 0x80000000u;
     if constexpr (sizeof(T) == 4) {
-      const v4ie_t r = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += __int_as_float(r[k]);
+      for (int k = 0; k < 4; ++k) v[k] += __int_as_float(res[k]);
     } else {
-      const v2i_t r = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
-      const f16x4 h = *reinterpret_cast<const f16x4*>(&r);
+      const v2i_t r2 = {res[0], res[1]};
+      const f16x4 h = *reinterpret_cast<const f16x4*>(&r2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] += (float)h[k];
     }

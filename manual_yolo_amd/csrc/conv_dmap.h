@@ -111,12 +111,18 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   uint32_t woff[NI - XI];
   int d_tile = first, d_ks = 0, d_slot = 0, d_issued = 0;
 
-  auto setup_tile = [&](int tile) {      // per-lane row state of `tile` (magic divisions only)
+  // Per-lane row state of `tile`.  DMA i of this wave covers rows 8*(wave + 8*i) + (lane >> 3) and the 8 lanes of a
+  // row group share a row, so computing per (lane, i) would do every row 8 times over.  Lane L computes ONE row -
+  // (i = (L >> 3) & 3, rsub = L & 7) - and the wave transposes with ds_bpermute: DMA i of lane L takes its values
+  // from lane 8*i + (L >> 3)  (profiles/r01_ws_kernel.md: the redundant form cost thousands of VALU cycles per tile).
+  const int bp_base = (lane >> 3) * 4;
+  auto setup_tile = [&](int tile) {
     const int mb = tile / NB, nb = tile - mb * NB;       // wave-uniform: scalar unit
     const int m0 = mb * BM, n0 = nb * BN;
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int m = m0 + 8 * (wave + 8 * i) + rsub;
+    int32_t c_off0, c_off1 = 0;
+    uint32_t c_inv;
+    {
+      const int m = m0 + 8 * (wave + 8 * ((lane >> 3) & (XI - 1))) + (lane & 7);
       const bool vm = m < a.M;
       const uint32_t mm = vm ? (uint32_t)m : 0u;
       const int b = (int)magic_div(mm, a.mg_hw_mul, a.mg_hw_shift);
@@ -125,19 +131,25 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       const int wo = (int)rem - ho * a.Wout;
       if constexpr (KS == 3) {
         const int hi0 = ho * a.stride - 1, wi0 = wo * a.stride - 1;
-        xoff0[i] = (((b * a.src[0].h + hi0) * a.src[0].w + wi0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
+        c_off0 = (((b * a.src[0].h + hi0) * a.src[0].w + wi0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
         // rows/cols of the 3x3 window inside the image -> 9-bit tap mask as an outer product
         const uint32_t hm = (hi0 >= 0 ? 1u : 0u) | 2u | ((hi0 + 2 < a.Hin) ? 4u : 0u);
         const uint32_t wm = (wi0 >= 0 ? 1u : 0u) | 2u | ((wi0 + 2 < a.Win) ? 4u : 0u);
-        uint32_t msk = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
-        xinv[i] = (vm ? (~msk & 0x1FFu) : 0x1FFu) | 0x200u;
+        const uint32_t msk = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? (wm << 3) : 0u) | ((hm & 4u) ? (wm << 6) : 0u);
+        c_inv = (vm ? (~msk & 0x1FFu) : 0x1FFu) | 0x200u;
       } else {
         const int h0 = a.src[0].up ? (ho >> 1) : ho, w0 = a.src[0].up ? (wo >> 1) : wo;
-        xoff0[i] = (((b * a.src[0].h + h0) * a.src[0].w + w0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
+        c_off0 = (((b * a.src[0].h + h0) * a.src[0].w + w0) * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T);
         const int h1 = a.src[1].up ? (ho >> 1) : ho, w1 = a.src[1].up ? (wo >> 1) : wo;
-        xoff1[i] = (((b * a.src[1].h + h1) * a.src[1].w + w1) * a.src[1].ld + a.src[1].ch_off) * (int)sizeof(T);
-        xinv[i] = vm ? 0u : kOob;
+        c_off1 = (((b * a.src[1].h + h1) * a.src[1].w + w1) * a.src[1].ld + a.src[1].ch_off) * (int)sizeof(T);
+        c_inv = vm ? 0u : kOob;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      xoff0[i] = __builtin_amdgcn_ds_bpermute(bp_base + i * 32, c_off0);
+      xinv[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + i * 32, (int)c_inv);
+      if constexpr (KS == 1) xoff1[i] = __builtin_amdgcn_ds_bpermute(bp_base + i * 32, c_off1);
     }
 #pragma unroll
     for (int i = 0; i < NI - XI; ++i) {
@@ -281,10 +293,18 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+          v4ie_t rv[TPW];
+          if (a.res) {                       // wave-uniform: all residual loads of this channel tile in flight together
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) rv[j] = epilogue_res_load<T>(a, rres, m0 + (wp * TPW + j) * 16 + frow, n);
+          } else {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) rv[j] = (v4ie_t){0, 0, 0, 0};
+          }
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
             const int m = m0 + (wp * TPW + j) * 16 + frow;
-            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, rres, m, n, acc[i][j], bv);
+            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, m, n, acc[i][j], bv, rv[j]);
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }

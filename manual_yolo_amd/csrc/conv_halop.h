@@ -224,7 +224,8 @@ __global__ __launch_bounds__(512) void conv_halop_kernel(const ConvArgs a, const
               bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-              epilogue_fast<T, OUTF32>(a, rdst, rres, m0 + mloc[j], n, acc[i][j], bv);
+              const v4ie_t rv = a.res ? epilogue_res_load<T>(a, rres, m0 + mloc[j], n) : (v4ie_t){0, 0, 0, 0};
+              epilogue_fast<T, OUTF32>(a, rdst, m0 + mloc[j], n, acc[i][j], bv, rv);
               acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
           }

@@ -402,10 +402,18 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+          v4ie_t rv[TPW];
+          if (a.res) {                       // wave-uniform: all residual loads of this channel tile in flight together
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) rv[j] = epilogue_res_load<T>(a, rres, m0 + (cm * TPW + j) * 16 + frow, n);
+          } else {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) rv[j] = (v4ie_t){0, 0, 0, 0};
+          }
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
             const int m = m0 + (cm * TPW + j) * 16 + frow;
-            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, rres, m, n, acc[i][j], bv);
+            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, m, n, acc[i][j], bv, rv[j]);
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
