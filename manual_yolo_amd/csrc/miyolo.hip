@@ -20,6 +20,7 @@
 #include "conv_dmap.h"
 #include "conv_halop.h"
 #include "conv_ws.h"
+#include "conv_dmh.h"
 #include "kernels_misc.h"
 #include "nms.h"
 
@@ -126,6 +127,17 @@ hipError_t set_dmap_attrs_ks() {
   MIYOLO_DMAP_ATTR(2, 6) MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
   MIYOLO_DMAP_ATTR(1, 2) MIYOLO_DMAP_ATTR(1, 1)
 #undef MIYOLO_DMAP_ATTR
+  return hipSuccess;
+}
+
+template <typename T, int KS>
+hipError_t set_dmh_attrs_ks() {
+  hipError_t e;
+#define MIYOLO_DMH_ATTR(WC, TC)                                                                         \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dmh_kernel<T, KS, WC, TC>),           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) return e;
+  MIYOLO_DMH_ATTR(2, 4) MIYOLO_DMH_ATTR(2, 3) MIYOLO_DMH_ATTR(1, 4) MIYOLO_DMH_ATTR(1, 3) MIYOLO_DMH_ATTR(1, 2) MIYOLO_DMH_ATTR(1, 1)
+#undef MIYOLO_DMH_ATTR
   return hipSuccess;
 }
 
@@ -312,7 +324,9 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
-      if (h->conv_impl == 5) HIP_TRY(h, launch_conv_ws<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      if ((h->conv_impl == 6 || (h->conv_impl == 3 && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
+        HIP_TRY(h, launch_conv_dmh<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      else if (h->conv_impl == 5) HIP_TRY(h, launch_conv_ws<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 4 && halop_eligible(a)) HIP_TRY(h, launch_conv_halop<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
@@ -380,8 +394,11 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
                     halo_xi(p.W / ob.down) <= 8;
   const bool halop = h->conv_impl == 4 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
                      (p.W / ob.down) <= 95 && op.cout % 4 == 0;
-  const int impl = h->conv_impl == 5 ? 5 : halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
-  ConvCfg c = impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
+  const int bk = 8 * (h->desc.dtype == MIYOLO_F16 ? 8 : 4);
+  const size_t dmh_lds = dmh_lds_bytes() + (size_t)((op.cin * op.ksize * op.ksize + bk - 1) / bk) * 32;
+  const bool dmh_auto = h->conv_impl == 3 && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
+  const int impl = (h->conv_impl == 6 || dmh_auto) ? 6 : h->conv_impl == 5 ? 5 : halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
+  ConvCfg c = impl == 6 ? pick_dma_cfg(op.cout, M) : impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
               : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
   if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
   return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 2323 = conv_halo_kernel<T,2,3>
@@ -487,6 +504,10 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_dmap_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_dmh_attrs_ks<float, 1>();
+  if (e == hipSuccess) e = set_dmh_attrs_ks<float, 3>();
+  if (e == hipSuccess) e = set_dmh_attrs_ks<half_t, 1>();
+  if (e == hipSuccess) e = set_dmh_attrs_ks<half_t, 3>();
   if (e == hipSuccess) e = set_ws_attrs_ks<float, 1>();
   if (e == hipSuccess) e = set_ws_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_ws_attrs_ks<half_t, 1>();

@@ -21,7 +21,7 @@ def ref_conv(x, w, b, s, act, res=None):
     return y + res if res is not None else y
 
 
-IMPLS = [0, 1, 2, 3, 4, 5]   # 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+IMPLS = [0, 1, 2, 3, 4, 5, 6]   # 6: half-size stages, two workgroups per CU (conv_dmh.h); 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
