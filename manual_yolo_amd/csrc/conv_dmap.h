@@ -20,6 +20,10 @@
 #include "common.h"
 #include "conv_dma.h"
 
+#ifndef MIYOLO_DMAP_INTERLEAVE
+#define MIYOLO_DMAP_INTERLEAVE 1
+#endif
+
 namespace miyolo {
 
 // Ring depth per tile shape: the 256 x 192 tile (56 KiB per stage) only fits twice; its steps are twice as
@@ -239,6 +243,62 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     }
   };
 
+  // The same step with the stage's DMAs spread between its MFMAs instead of issued as a burst before them: a burst
+  // of NI x 8 DMAs backs up the CU's vector-memory queue and every wave stalls in issue (~900 cycles per step,
+  // profiles/r01_conv_stamps.md) while the matrix pipe idles; one DMA every few MFMAs keeps both busy.
+  auto compute_issue = [&](int slot, const bool do_issue) {
+    const uint32_t st = lds_base + (uint32_t)(d_slot * STAGE + wave * 1024);
+    const int ks = d_ks;
+    const uint32_t e = ktab[ks * 8 + cg];
+    const uint32_t tp = e >> 28;
+    const uint32_t kofs = (KS == 3) ? (e & 0x0FFFFFFFu) : (e & 0x8FFFFFFFu);
+    const bool seg1 = (KS == 1) && (ks * 8) >= ct0;
+    auto issue_one = [&](int d) {
+      if (d < XI) {
+        if constexpr (KS == 3) {
+          lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | (((xinv[d] >> tp) & 1u) << 31));
+        } else {
+          if (!seg1) lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | xinv[d]);
+          else lds_dma16(rs1, st + d * 8192, ((uint32_t)xoff1[KS == 1 ? d : 0] + kofs) | xinv[d]);
+        }
+      } else {
+        lds_dma16(rsw, st + BM * ROW_BYTES + (d - XI) * 8192, woff[d - XI] + (uint32_t)(ks * 128));
+      }
+    };
+    constexpr int NM = 2 * TC * TPW;                 // MFMAs of the step
+    const unsigned char* xs = smem + slot * STAGE;
+    const unsigned char* ws = xs + BM * ROW_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[TC], bf[TPW];
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+        af[i] = *reinterpret_cast<const uint4*>(ws + lds_off((wc * TC + i) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < TPW; ++j)
+        bf[j] = *reinterpret_cast<const uint4*>(xs + lds_off((wp * TPW + j) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          Mma<T>::run(af[i], bf[j], acc[i][j]);
+          const int q = (kk * TC + i) * TPW + j;     // constant after unrolling
+#pragma unroll
+          for (int d = 0; d < NI; ++d)
+            if (q == (d * NM) / NI) { if (do_issue) issue_one(d); }
+        }
+    }
+    if (do_issue) {
+      d_slot = (d_slot == NST - 1) ? 0 : d_slot + 1;
+      ++d_issued;
+      if (++d_ks == a.nk) {
+        d_ks = 0;
+        d_tile += G;
+        if (d_tile < ntiles) setup_tile(d_tile);
+      }
+    }
+  };
+
   // ---- stream: prologue issues two stages, then one barrier + one issue + one compute per step
   setup_tile(d_tile);
   issue_next();
@@ -262,9 +322,14 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     // second, so that the vector-memory path and the matrix pipe overlap across SIMD partners,
     // made every layer 20-25 % slower - the LDS-DMA writes and the partner's ds_reads/MFMA issue
     // interfere.)
-    if (d_issued < total_steps) issue_next();
-    STAMP(t2);
-    compute(c_slot);
+    if constexpr (MIYOLO_DMAP_INTERLEAVE && NST > 2) {      // measured: -3...-9 % on the 3-slot 3x3 shapes, +4 % on the 2-slot 256x192 tile
+      STAMP(t2);
+      compute_issue(c_slot, d_issued < total_steps);
+    } else {
+      if (d_issued < total_steps) issue_next();
+      STAMP(t2);
+      compute(c_slot);
+    }
     STAMP(t3);
 #if MIYOLO_ABLATE
     acc_wait += t1 - t0; acc_issue += t2 - t1; acc_comp += t3 - t2;
