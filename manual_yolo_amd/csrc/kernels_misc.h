@@ -25,6 +25,7 @@ struct StemArgs {
   void* out;           // [B,H/2,W/2,cout] T
   int32_t B, H, W, Ho, Wo, cout, act, exact;
   uint32_t in_bytes;
+  uint32_t mg_hw_mul, mg_hw_shift, mg_w_mul, mg_w_shift;   // host_magic(Ho*Wo), host_magic(Wo): no 64-bit divides per tile
 };
 
 template <typename T, int TCS>
@@ -53,10 +54,11 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   for (long tile = wave_global; tile < ntiles; tile += nwaves) {
     const long m = tile * 16 + frow;
     const bool vm = m < total;
-    const long mm = vm ? m : 0;
-    const int wo = (int)(mm % a.Wo);
-    const long t2 = mm / a.Wo;
-    const int ho = (int)(t2 % a.Ho), b = (int)(t2 / a.Ho);
+    const uint32_t mm = vm ? (uint32_t)m : 0u;                 // total < 2^31 (engine: buffers below 2 GiB)
+    const int b = (int)magic_div(mm, a.mg_hw_mul, a.mg_hw_shift);
+    const uint32_t rem = mm - (uint32_t)b * (uint32_t)(a.Ho * a.Wo);
+    const int ho = (int)magic_div(rem, a.mg_w_mul, a.mg_w_shift);
+    const int wo = (int)rem - ho * a.Wo;
     const int wi0 = 2 * wo - 1, hi0 = 2 * ho - 1;
     float x[8];
 #pragma unroll
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
       const int bo = (q < 3) ? j : 8;
       const int wi = wi0 + bo / 3;
       const bool ok = vm && (q < 3 || j < 3) && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      const uint32_t off = ok ? (uint32_t)((((long)b * a.H + hi) * a.W + wi0) * 3 + bo) : 0x80000000u;
+      const uint32_t off = ok ? (uint32_t)(((b * a.H + hi) * a.W + wi0) * 3 + bo) : 0x80000000u;   // < 2^31: checked by the host
       const uint32_t u = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
       x[j] = a.exact ? (float)u / 255.0f : (float)u * (1.0f / 255.0f);   // f16: rounded to half right after
     }

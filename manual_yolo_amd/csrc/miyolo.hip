@@ -258,6 +258,8 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.cout = op.cout; a.act = op.act; a.exact = (h->desc.dtype == MIYOLO_F32);
       if ((size_t)Bc * H * W * 3 >= ((size_t)1 << 31)) return fail(h, MIYOLO_ERR_SHAPE, "input batch exceeds 2 GiB per pass");
       a.in_bytes = (uint32_t)((size_t)Bc * H * W * 3);
+      host_magic((uint32_t)(a.Ho * a.Wo), &a.mg_hw_mul, &a.mg_hw_shift);
+      host_magic((uint32_t)a.Wo, &a.mg_w_mul, &a.mg_w_shift);
       if (op.cout % 16 || op.cout > 80 || op.dst.ch_off != 0 || ob.channels != op.cout || ob.down != 2)
         return fail(h, MIYOLO_ERR_UNSUPPORTED, "stem: cout=%d must be a multiple of 16 (<= 80) and own its buffer", op.cout);
       const long ntiles = ((long)Bc * a.Ho * a.Wo + 15) / 16;
