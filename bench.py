@@ -216,6 +216,12 @@ def main():
 
     if rank == 0:
         fl_step, by_step = eng.work(B, H, W)
+        # layer-wise mixed roofline of the whole step, t_min = sum over ops of
+        # max(flops / dense MFMA peak, compulsory bytes / HBM peak); model_roofline_frac = t_min / measured step
+        t_min = 0.0
+        for i in range(len(eng.prog.ops)):
+            fl_i, by_i = eng.op_work(i, B, H, W)
+            t_min += max(fl_i / (PEAK_TFLOPS[args.dtype] * 1e12), by_i / (HBM_PEAK_GBS * 1e9))
         line = {
             "metric": "frames/sec whole-node, yolov8m@640 batch=64; mAP delta vs CPU ref" if task == "detect"
                       else "images/sec, yolov8n-cls rank classifier 64x64",
@@ -228,7 +234,8 @@ def main():
                                    if task == "detect" else f"yolov8n-cls rank_classifier weights 64x64, batch {B}/GPU",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "gflop_per_frame": round(fl_step / B / 1e9, 3), "algorithmic_mb_per_frame": round(by_step / B / 1e6, 2),
-                       "model_tflops": round(fl_step * world / (ms_per_step * 1e-3) / 1e12, 2)},
+                       "model_tflops": round(fl_step * world / (ms_per_step * 1e-3) / 1e12, 2),
+                       "model_t_min_ms": round(t_min * 1e3, 4), "model_roofline_frac": round(t_min * 1e3 / ms_per_step, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

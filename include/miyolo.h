@@ -195,6 +195,15 @@ int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* f
  * inputs once, writes its output once, weights once per batch). */
 int miyolo_work(miyolo_handle h, int B, int H, int W, double* flops, double* bytes);
 
+/* Detect pre-processing on the device: what the reference's `model(frame)` does first
+ * (detect.py:541 -> [3P] LetterBox: cv2.resize INTER_LINEAR to new_w x new_h, constant pad to dst_w x dst_h).
+ * src: device uint8 [B][src_h][src_w][3], dst: device uint8 [B][dst_h][dst_w][3]; the resized image lands at
+ * (top, left), everything else is pad_value (114).  The host computes the geometry exactly as LetterBox does
+ * (manual_yolo_amd/preprocess.py letterbox_geometry).  Bit-exact against oracle/pre_ref.py letterbox.  Stateless
+ * (no handle); errors are reported through miyolo_last_error(NULL).  Asynchronous on `stream`. */
+int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, int dst_h, int dst_w, int top, int left,
+                     int new_h, int new_w, int pad_value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@
 #include "conv_dmh.h"
 #include "kernels_misc.h"
 #include "nms.h"
+#include "preprocess.h"
 
 using namespace miyolo;
 
@@ -774,6 +775,24 @@ int miyolo_work(miyolo_handle h, int B, int H, int W, double* flops, double* byt
   }
   if (flops) *flops = fl;
   if (bytes) *bytes = by;
+  return 0;
+}
+
+int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, int dst_h, int dst_w, int top, int left,
+                     int new_h, int new_w, int pad_value, void* stream) {
+  if (!src || !dst || B < 1 || src_h < 1 || src_w < 1 || new_h < 1 || new_w < 1 || top < 0 || left < 0 ||
+      top + new_h > dst_h || left + new_w > dst_w || pad_value < 0 || pad_value > 255)
+    return fail(nullptr, MIYOLO_ERR_ARG, "letterbox: bad geometry %dx%d -> %dx%d at (%d,%d) in %dx%d", src_h, src_w, new_h, new_w,
+                top, left, dst_h, dst_w);
+  LetterboxArgs a;
+  a.src = static_cast<const uint8_t*>(src); a.dst = static_cast<uint8_t*>(dst);
+  a.B = B; a.sh = src_h; a.sw = src_w; a.dh = dst_h; a.dw = dst_w; a.top = top; a.left = left; a.nh = new_h; a.nw = new_w;
+  a.pad = pad_value;
+  a.scale_x = (double)src_w / (double)new_w;
+  a.scale_y = (double)src_h / (double)new_h;
+  hipLaunchKernelGGL(letterbox_kernel, dim3((dst_w + 63) / 64, (dst_h + 3) / 4, B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "letterbox launch: %s", hipGetErrorString(e));
   return 0;
 }
 

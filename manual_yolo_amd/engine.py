@@ -69,6 +69,7 @@ SYMBOLS = {
     "miyolo_op_work": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "miyolo_profile_read": (_i, [_vp, _i, _vp, _vp, _vp]),
     "miyolo_debug_stamps": (_i, [_vp, _vp]),
+    "miyolo_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -23,7 +23,7 @@ import torch
 
 from .ckpt import load_weights
 from .engine import Engine, engine_from_weights
-from .preprocess import classify_transform_bgr, letterbox_batch, scale_params
+from .preprocess import classify_transform_bgr, letterbox_batch, letterbox_batch_gpu, scale_params
 from .results import Results
 
 
@@ -95,9 +95,14 @@ class YOLO:
             imgsz = (imgsz, imgsz)
         t0 = time.perf_counter()
         if self.task == "detect":
-            batch = letterbox_batch(frames, tuple(imgsz), 32)
-            x = torch.from_numpy(batch).to(eng.device, non_blocking=True)
-            net_hw = batch.shape[1:3]
+            if len({f.shape for f in frames}) == 1:
+                # one shape (a video stream): raw frames go up once, resize + pad run on the GPU (miyolo_letterbox)
+                x = letterbox_batch_gpu(frames, tuple(imgsz), 32, auto=True, device=eng.device)
+                net_hw = tuple(x.shape[1:3])
+            else:                                   # mixed shapes: the reference pads to the square on the host
+                batch = letterbox_batch(frames, tuple(imgsz), 32)
+                x = torch.from_numpy(batch).to(eng.device, non_blocking=True)
+                net_hw = batch.shape[1:3]
             scale = torch.tensor([scale_params(net_hw, f.shape[:2]) for f in frames], dtype=torch.float32,
                                  device=eng.device)
             torch.cuda.synchronize(eng.device)

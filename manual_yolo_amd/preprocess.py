@@ -64,6 +64,49 @@ def letterbox(img: np.ndarray, new_shape: Tuple[int, int], auto: bool, stride: i
     return out
 
 
+def letterbox_geometry(shape_hw: Tuple[int, int], new_shape: Tuple[int, int], auto: bool, stride: int = 32):
+    """(new_h, new_w, top, left, out_h, out_w) exactly as [3P] LetterBox derives them (same arithmetic as
+    ``letterbox`` above)."""
+    h0, w0 = shape_hw
+    r = min(new_shape[0] / h0, new_shape[1] / w0)
+    new_w, new_h = int(round(w0 * r)), int(round(h0 * r))
+    dw, dh = new_shape[1] - new_w, new_shape[0] - new_h
+    if auto:
+        dw, dh = dw % stride, dh % stride
+    dw, dh = dw / 2, dh / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return new_h, new_w, top, left, new_h + top + bottom, new_w + left + right
+
+
+def letterbox_batch_gpu(frames, imgsz: Tuple[int, int], stride: int = 32, auto: bool = True, device=None, pad_value: int = 114):
+    """Same-shape BGR uint8 frames -> letterboxed device tensor [B, H, W, 3] uint8, resized and padded by the HIP
+    kernel behind ``miyolo_letterbox`` (bit-exact against oracle/pre_ref.py).  ``frames``: a list of HxWx3 numpy
+    arrays of one shape, or a uint8 tensor [B, h, w, 3] (host or device).  Raises if the extension is missing."""
+    import torch
+    from .engine import MiyoloError, load_library
+    lib = load_library()
+    if isinstance(frames, torch.Tensor):
+        src = frames
+    else:
+        if len({f.shape for f in frames}) != 1:
+            raise ValueError("letterbox_batch_gpu needs frames of one shape (the reference pads mixed batches to the square on the host)")
+        src = torch.from_numpy(np.ascontiguousarray(np.stack(frames)))
+    if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[3] != 3:
+        raise ValueError("frames must be uint8 [B, h, w, 3]")
+    dev = torch.device(device if device is not None else (src.device if src.is_cuda else "cuda:0"))
+    src = src.to(dev).contiguous()
+    B, h0, w0 = int(src.shape[0]), int(src.shape[1]), int(src.shape[2])
+    nh, nw, top, left, oh, ow = letterbox_geometry((h0, w0), tuple(imgsz), auto, stride)
+    dst = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.miyolo_letterbox(src.data_ptr(), B, h0, w0, dst.data_ptr(), oh, ow, top, left, nh, nw, pad_value,
+                                  torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        raise MiyoloError(f"miyolo_letterbox failed ({rc}): {lib.miyolo_last_error(None).decode()}")
+    return dst
+
+
 def letterbox_batch(frames: Sequence[np.ndarray], imgsz: Tuple[int, int], stride: int = 32) -> np.ndarray:
     """[3P] DetectionPredictor.pre_transform: rect (``auto``) padding only when every frame of
     the batch has the same shape, otherwise pad to the full square."""
