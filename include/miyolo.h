@@ -204,6 +204,15 @@ int miyolo_work(miyolo_handle h, int B, int H, int W, double* flops, double* byt
 int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, int dst_h, int dst_w, int top, int left,
                      int new_h, int new_w, int pad_value, void* stream);
 
+/* Classifier input on the device, fused with the crop: for each box, what the reference does
+ * between a detection and `rank_model(crop)` (detect.py:100-113 safe_crop, detect.py:121 -> the checkpoint's pickled
+ * transforms Resize(size, bilinear, antialias) + CenterCrop(size), i.e. Pillow's 8-bit resample).
+ * frame: device uint8 [H][W][3]; boxes: device int32 [n][4] = x1,y1,x2,y2 already clamped to the frame (safe_crop's
+ * arithmetic is the host's, manual_yolo_amd/chain.py); out: device uint8 [n][size][size][3], same channel order as the
+ * frame.  max_short: largest min(width, height) over the boxes (<= 640).  Byte-exact against PIL
+ * (tests/test_gpu_preprocess.py).  Stateless; errors through miyolo_last_error(NULL).  Asynchronous on `stream`. */
+int miyolo_crop_resize(const void* frame, int H, int W, const int32_t* boxes, int n, int size, int max_short, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

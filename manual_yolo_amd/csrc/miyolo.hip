@@ -796,4 +796,28 @@ int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, in
   return 0;
 }
 
+int miyolo_crop_resize(const void* frame, int H, int W, const int32_t* boxes, int n, int size, int max_short, void* out, void* stream) {
+  if (!frame || !boxes || !out || H < 1 || W < 1 || n < 0 || size < 8 || size > 128 || max_short < 1)
+    return fail(nullptr, MIYOLO_ERR_ARG, "crop_resize: bad arguments");
+  if (max_short > kCrMaxShort)
+    return fail(nullptr, MIYOLO_ERR_UNSUPPORTED, "crop_resize: crops with a short side above %d px are not supported (got %d)", kCrMaxShort, max_short);
+  if (n == 0) return 0;
+  CropResizeArgs a;
+  a.frame = static_cast<const uint8_t*>(frame); a.boxes = boxes; a.out = static_cast<uint8_t*>(out);
+  a.H = H; a.W = W; a.n = n; a.S = size;
+  a.tmp_rows = max_short + 2 * ((max_short + size - 1) / size) + 8;      // rows the vertical pass of S outputs can touch
+  const size_t lds = crop_resize_lds_bytes(size, a.tmp_rows);
+  if (lds > 160 * 1024) return fail(nullptr, MIYOLO_ERR_UNSUPPORTED, "crop_resize: %zu bytes of LDS needed", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crop_resize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "crop_resize attribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(n), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "crop_resize launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // extern "C"

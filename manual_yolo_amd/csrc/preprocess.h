@@ -61,3 +61,129 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const LetterboxArgs a) {
 }
 
 }  // namespace miyolo
+
+// ----------------------------------------------------------------------------------------------------------------
+// crop_resize_kernel: the classifier's input transform on the device, fused with the crop (SURVEY.md 8f rank 1
+// second half + rank 2; reference detect.py:100-113 safe_crop, detect.py:121 rank_model(crop) -> the pickled
+// torchvision Compose[Resize(64, bilinear, antialias), CenterCrop(64)], i.e. Pillow's 8-bit resample).
+// One workgroup per box: out[n] = centre_crop(PIL_resize(frame[y1:y2, x1:x2], short side -> S), S).
+// Pillow's algorithm (src/libImaging/Resample.c; restated and checked against PIL in oracle/pre_ref.py):
+//   window [int(c - s + .5), int(c + s + .5)) around c = (xx + .5) * scale, s = max(scale, 1), triangle weights
+//   normalised in double, 22-bit fixed point (round half away from zero), horizontal pass -> 8-bit intermediate ->
+//   vertical pass, each  clip8((2^21 + sum px * k) >> 22).
+// Only the 64 output columns / rows that survive the centre crop are computed.  Byte-exact.
+namespace miyolo {
+
+constexpr int kCrKMax = 24;          // taps per output sample: ceil(max(scale,1)) * 2 + 1 <= 21 for scale <= 10
+constexpr int kCrMaxShort = 640;     // short side of a crop (scale <= 10 at S = 64)
+
+struct CropResizeArgs {
+  const uint8_t* frame;   // [H][W][3]
+  const int32_t* boxes;   // [n][4] x1, y1, x2, y2 (already clamped: 0 <= x1 < x2 <= W, 0 <= y1 < y2 <= H)
+  uint8_t* out;           // [n][S][S][3]
+  int32_t H, W, n, S, tmp_rows;
+};
+
+// window and fixed-point coefficients of output sample xx of a Pillow bilinear resample in_size -> out_size
+__device__ __forceinline__ void pil_coeffs(int in_size, int out_size, int xx, int* xmin_o, int* cnt_o, int* kk) {
+  const double scale = (double)((float)in_size - 0.0f) / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const double ss = 1.0 / filterscale;
+  const double center = 0.0 + ((double)xx + 0.5) * scale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  if (xmax > kCrKMax) xmax = kCrKMax;          // cannot happen for scale <= 10 (host checks); keeps the table in bounds
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) {
+    double a = ((double)(x + xmin) - center + 0.5) * ss;
+    if (a < 0.0) a = -a;
+    ww += (a < 1.0) ? 1.0 - a : 0.0;
+  }
+  for (int x = 0; x < xmax; ++x) {
+    double a = ((double)(x + xmin) - center + 0.5) * ss;
+    if (a < 0.0) a = -a;
+    double w = (a < 1.0) ? 1.0 - a : 0.0;
+    if (ww != 0.0) w = w / ww;
+    kk[x] = (w < 0.0) ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0);
+  }
+  *xmin_o = xmin;
+  *cnt_o = xmax;
+}
+
+__global__ __launch_bounds__(256) void crop_resize_kernel(const CropResizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char crs[];
+  const int S = a.S, tid = threadIdx.x, b = blockIdx.x;
+  int* hk = reinterpret_cast<int*>(crs);                 // [S][kCrKMax] horizontal coefficients
+  int* vk = hk + S * kCrKMax;                            // [S][kCrKMax] vertical
+  int* hb = vk + S * kCrKMax;                            // [S][2] xmin, count
+  int* vb = hb + S * 2;
+  uint8_t* tmp = reinterpret_cast<uint8_t*>(vb + S * 2); // [tmp_rows][S][3] horizontal-pass image
+
+  const int x1 = a.boxes[b * 4 + 0], y1 = a.boxes[b * 4 + 1], x2 = a.boxes[b * 4 + 2], y2 = a.boxes[b * 4 + 3];
+  const int cw = x2 - x1, ch = y2 - y1;
+  int rw, rh;                                            // size after the short-side resize
+  if ((cw <= ch && cw == S) || (ch <= cw && ch == S)) { rw = cw; rh = ch; }
+  else if (cw < ch) { rw = S; rh = (int)((double)(S * ch) / (double)cw); }
+  else { rw = (int)((double)(S * cw) / (double)ch); rh = S; }
+  const int top = (int)rint((double)(rh - S) / 2.0), left = (int)rint((double)(rw - S) / 2.0);   // Python round(): half to even
+  const bool need_h = rw != cw, need_v = rh != ch;
+
+  if (tid < S) {
+    if (need_h) pil_coeffs(cw, rw, left + tid, &hb[tid * 2], &hb[tid * 2 + 1], hk + tid * kCrKMax);
+    else { hb[tid * 2] = left + tid; hb[tid * 2 + 1] = 1; hk[tid * kCrKMax] = 1 << 22; }
+  } else if (tid < 2 * S) {
+    const int t = tid - S;
+    if (need_v) pil_coeffs(ch, rh, top + t, &vb[t * 2], &vb[t * 2 + 1], vk + t * kCrKMax);
+    else { vb[t * 2] = top + t; vb[t * 2 + 1] = 1; vk[t * kCrKMax] = 1 << 22; }
+  }
+  __syncthreads();
+  const int rmin = vb[0];                                               // source rows the vertical pass touches
+  const int rmax = vb[(S - 1) * 2] + vb[(S - 1) * 2 + 1];
+  const int nrows = min(rmax - rmin, a.tmp_rows);
+
+  // horizontal pass: tmp[r][c] for r in [rmin, rmax), c in [0, S)
+  for (int it = tid; it < nrows * S; it += 256) {
+    const int r = it / S, c = it - r * S;
+    const int xmin = hb[c * 2], cnt = hb[c * 2 + 1];
+    const uint8_t* sp = a.frame + ((size_t)(y1 + rmin + r) * a.W + (x1 + xmin)) * 3;
+    const int* k = hk + c * kCrKMax;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int x = 0; x < cnt; ++x) {
+      const int kv = k[x];
+      s0 += (int)sp[x * 3 + 0] * kv; s1 += (int)sp[x * 3 + 1] * kv; s2 += (int)sp[x * 3 + 2] * kv;
+    }
+    s0 >>= 22; s1 >>= 22; s2 >>= 22;
+    uint8_t* t = tmp + ((size_t)r * S + c) * 3;
+    t[0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+    t[1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+    t[2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+  }
+  __syncthreads();
+  // vertical pass
+  uint8_t* o = a.out + (size_t)b * S * S * 3;
+  for (int it = tid; it < S * S; it += 256) {
+    const int oy = it / S, ox = it - oy * S;
+    const int ymin = vb[oy * 2] - rmin, cnt = vb[oy * 2 + 1];
+    const int* k = vk + oy * kCrKMax;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int y = 0; y < cnt; ++y) {
+      const int kv = k[y];
+      const uint8_t* t = tmp + ((size_t)(ymin + y) * S + ox) * 3;
+      s0 += (int)t[0] * kv; s1 += (int)t[1] * kv; s2 += (int)t[2] * kv;
+    }
+    s0 >>= 22; s1 >>= 22; s2 >>= 22;
+    o[it * 3 + 0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+    o[it * 3 + 1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+    o[it * 3 + 2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+  }
+}
+
+inline size_t crop_resize_lds_bytes(int S, int tmp_rows) {
+  return (size_t)S * kCrKMax * 4 * 2 + (size_t)S * 2 * 4 * 2 + (size_t)tmp_rows * S * 3;
+}
+
+}  // namespace miyolo

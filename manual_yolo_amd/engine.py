@@ -70,6 +70,7 @@ SYMBOLS = {
     "miyolo_profile_read": (_i, [_vp, _i, _vp, _vp, _vp]),
     "miyolo_debug_stamps": (_i, [_vp, _vp]),
     "miyolo_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "miyolo_crop_resize": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -129,6 +129,17 @@ class Probs(_TensorBox):
         return self.data[self.top5]
 
 
+class Detections:
+    """Plain carrier with the fields of ``supervision.Detections`` that the reference reads (``detect.py:542-557,580-584``)."""
+
+    def __init__(self, xyxy, confidence, class_id, tracker_id=None, data=None):
+        self.xyxy, self.confidence, self.class_id, self.tracker_id, self.data = xyxy, confidence, class_id, tracker_id, data or {}
+        self.mask = None
+
+    def __len__(self):
+        return int(self.xyxy.shape[0])
+
+
 class Results:
     def __init__(self, orig_img, path: str, names: Dict[int, str], boxes=None, probs=None,
                  speed: Optional[dict] = None, anchor_idx=None):
@@ -158,6 +169,20 @@ class Results:
         r.probs = self.probs.cpu() if self.probs is not None else None
         r.anchor_idx = self.anchor_idx
         return r
+
+    def to_detections(self) -> "Detections":
+        """What ``sv.Detections.from_ultralytics(results)`` extracts (reference ``detect.py:542``):
+        numpy ``xyxy [n,4] f32``, ``confidence [n]``, ``class_id [n] int``, ``tracker_id`` (None), ``data['class_name']``,
+        in NMS keep order (descending confidence) - the tuple ByteTrack / the reference's annotators consume.
+        ``supervision`` itself reads the same attributes (``boxes.xyxy/.conf/.cls/.id``, ``names``, ``masks``, ``obb``),
+        so ``sv.Detections.from_ultralytics`` also works on this object unchanged."""
+        if self.boxes is None:
+            raise AttributeError("classification results carry no boxes")
+        b = self.boxes.cpu()
+        class_id = b.cls.numpy().astype(int)
+        return Detections(xyxy=b.xyxy.numpy(), confidence=b.conf.numpy(), class_id=class_id,
+                          tracker_id=b.id.int().numpy() if b.id is not None else None,
+                          data={"class_name": np.array([self.names[int(i)] for i in class_id])})
 
     def summary(self):
         out = []

@@ -101,3 +101,84 @@ def letterbox(img: np.ndarray, new_shape=(640, 640), auto: bool = True, stride: 
                   pad_value, dtype=np.uint8)
     out[top:top + img.shape[0], left:left + img.shape[1]] = img
     return out, out.shape[:2]
+
+
+# ----------------------------------------------------------------------------------------------------
+# Pillow's 8-bit resample, restated (test infrastructure: checked against PIL itself in tests/test_oracle_kat.py,
+# and the reference for the device kernel behind miyolo_crop_resize).  Follows Pillow src/libImaging/Resample.c:
+# precompute_coeffs (support = filter support x max(scale, 1), window [int(c - s + .5), int(c + s + .5)),
+# weights normalised in double), normalize_coeffs_8bpc (22-bit fixed point, round half away from zero),
+# ImagingResampleHorizontal_8bpc then ImagingResampleVertical_8bpc with an 8-bit intermediate image.
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_coeffs(in_size: int, out_size: int):
+    scale = float(np.float32(in_size) - np.float32(0)) / out_size        # (double)(in1 - in0) / outSize, in0/in1 are C floats
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale                                          # bilinear: support 1.0
+    ss = 1.0 / filterscale
+    bounds, coefs = [], []
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = []
+        ww = 0.0
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            if a < 0.0:
+                a = -a
+            w = 1.0 - a if a < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        if ww != 0.0:
+            k = [v / ww for v in k]
+        kk = [int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS)) for v in k]
+        bounds.append((xmin, xmax))
+        coefs.append(kk)
+    return bounds, coefs
+
+
+def _pil_pass(src: np.ndarray, out_size: int) -> np.ndarray:
+    """Resample axis 1 of src [rows][in][C] uint8 to out_size."""
+    bounds, coefs = _pil_coeffs(src.shape[1], out_size)
+    out = np.empty((src.shape[0], out_size, src.shape[2]), dtype=np.uint8)
+    s = src.astype(np.int64)
+    for xx, ((xmin, xmax), kk) in enumerate(zip(bounds, coefs)):
+        acc = np.full((src.shape[0], src.shape[2]), 1 << (_PIL_PRECISION_BITS - 1), dtype=np.int64)
+        for x in range(xmax):
+            acc += s[:, xmin + x, :] * kk[x]
+        out[:, xx, :] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_resize_bilinear_u8(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
+    """Image.fromarray(img).resize(size_wh, Image.BILINEAR) for uint8 HxWx3 (antialiased when shrinking)."""
+    ow, oh = size_wh
+    h, w = img.shape[:2]
+    cur = img
+    if ow != w:
+        cur = _pil_pass(cur, ow)                                         # horizontal first, 8-bit intermediate
+    if oh != h:
+        cur = _pil_pass(cur.transpose(1, 0, 2), oh).transpose(1, 0, 2)   # then vertical
+    return np.ascontiguousarray(cur)
+
+
+def classify_transform_restated(img: np.ndarray, size: int = 64) -> np.ndarray:
+    """classify_transform without PIL: short side -> size (long = int(size * long / short)), centre crop.
+    Same channel order in and out.  Only the shapes the reference path produces (no side shorter than `size`
+    after the resize, i.e. no padding branch)."""
+    h, w = img.shape[:2]
+    if not ((w <= h and w == size) or (h <= w and h == size)):
+        if w < h:
+            img = pil_resize_bilinear_u8(img, (size, int(size * h / w)))
+        else:
+            img = pil_resize_bilinear_u8(img, (int(size * w / h), size))
+    h, w = img.shape[:2]
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    return np.ascontiguousarray(img[top:top + size, left:left + size])

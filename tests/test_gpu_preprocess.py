@@ -45,3 +45,59 @@ def test_letterbox_device_tensor_input_and_errors():
         letterbox_batch_gpu([np.zeros((8, 8, 3), np.uint8), np.zeros((9, 8, 3), np.uint8)], (64, 64))
     with pytest.raises(ValueError):
         letterbox_batch_gpu(torch.zeros((1, 8, 8, 3)), (64, 64))
+
+
+# --------------------------------------------------------------------------- crop + classifier transform on the device
+def _frame(h, w, seed):
+    rng = np.random.default_rng(seed)
+    f = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    f[::9, ::4] = 255
+    f[5::11] //= 3
+    return f
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_crop_resize_byte_exact_against_pil(seed):
+    """miyolo_crop_resize vs PIL itself (classify_transform_bgr): small crops (upscaled, as the rank boxes are),
+    large ones (antialiased shrink up to 10x), extreme aspect ratios, crops that need no resize on one axis."""
+    from manual_yolo_amd.chain import crops_to_classifier_input
+    from manual_yolo_amd.preprocess import classify_transform_bgr
+    frame = _frame(930, 1130, seed)
+    boxes = [(10, 20, 47, 72), (100, 100, 152, 137), (0, 0, 48, 48), (300, 40, 364, 120), (300, 40, 380, 104), (500, 500, 564, 564),
+             (5, 5, 34, 305), (600, 10, 1130, 330), (0, 200, 640, 930), (700, 700, 707, 709), (1129, 929, 1130, 930),
+             (200, 300, 861, 930), (40, 60, 171, 121)]
+    y = crops_to_classifier_input(frame, boxes, 64).cpu().numpy()
+    for i, (x1, y1, x2, y2) in enumerate(boxes):
+        ref = classify_transform_bgr(frame[y1:y2, x1:x2], 64)
+        assert np.array_equal(y[i], ref), (boxes[i], int(np.abs(y[i].astype(int) - ref.astype(int)).max()))
+
+
+def test_crop_resize_argument_checks():
+    from manual_yolo_amd.chain import crops_to_classifier_input
+    from manual_yolo_amd.engine import MiyoloError
+    frame = _frame(900, 900, 2)
+    assert crops_to_classifier_input(frame, [], 64).shape == (0, 64, 64, 3)
+    with pytest.raises(ValueError):
+        crops_to_classifier_input(frame, [(10, 10, 5, 20)], 64)
+    with pytest.raises(MiyoloError):
+        crops_to_classifier_input(frame, [(0, 0, 700, 800)], 64)          # short side 700 > 640
+
+
+def test_classify_boxes_equals_per_crop_calls(golden_dir):
+    """chain.classify_boxes (one crop kernel + one classifier batch) == rank_model(safe_crop(...)) per box, the
+    loop of detect.py:580-588 / 121-125: same top1, identical probabilities."""
+    import os
+    from manual_yolo_amd import YOLO
+    from manual_yolo_amd.chain import classify_boxes, safe_crop_box
+    rank_model = YOLO(os.path.join(golden_dir, "rank_best.safetensors"))
+    frame = _frame(930, 1130, 5)
+    xyxy = np.array([[100.4, 200.9, 140.2, 262.0], [5, 5, 30, 44], [900, 700, 960, 790], [50, 10, 30, 20], [1100, 900, 1140, 940]], dtype=np.float32)
+    got = classify_boxes(rank_model, frame, xyxy, pad=6)
+    assert got[3] is None
+    for i, b in enumerate(xyxy):
+        sb = safe_crop_box(frame.shape[:2], *b, 6)
+        if sb is None:
+            continue
+        r = rank_model(frame[sb[1]:sb[3], sb[0]:sb[2]])[0]
+        assert got[i][0] == r.probs.top1
+        assert np.allclose(got[i][2], r.probs.data.cpu().numpy(), rtol=0, atol=1e-6)

@@ -83,3 +83,29 @@ def test_nc_quirk_changes_stem_width():
     # upstream parse_model leaves a channel count equal to nc unscaled (see parse_spec docstring)
     assert parse_spec(YOLOV8_DET_SPEC, 64, "m", nc_quirk=True)[0]["c2"] == 64
     assert parse_spec(YOLOV8_DET_SPEC, 64, "m", nc_quirk=False)[0]["c2"] == 48
+
+
+def test_pillow_resample_restatement_is_pinned_against_pil():
+    """oracle/pre_ref.py restates Pillow's 8-bit bilinear resample (the classifier's Resize transform) so that the
+    device kernel can be checked without PIL in the loop; here the restatement itself is checked against PIL."""
+    from PIL import Image
+    from oracle.pre_ref import classify_transform_restated, pil_resize_bilinear_u8
+    rng = np.random.default_rng(0)
+    for (h, w), (ow, oh) in [((37, 52), (64, 90)), ((120, 47), (64, 163)), ((200, 300), (96, 64)), ((64, 64), (64, 64)),
+                             ((31, 33), (64, 68)), ((500, 260), (64, 123)), ((17, 400), (1505, 64))]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(pil_resize_bilinear_u8(img, (ow, oh)), ref), ((h, w), (ow, oh))
+    for h, w in [(37, 52), (52, 37), (48, 48), (130, 61), (64, 80), (80, 64), (64, 64), (29, 300), (640, 700)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(classify_transform_restated(img, 64), classify_transform(img, 64)), (h, w)
+
+
+def test_safe_crop_box_matches_reference_arithmetic():
+    """manual_yolo_amd/chain.py safe_crop_box = the index arithmetic of detect.py:100-113."""
+    from manual_yolo_amd.chain import safe_crop_box
+    assert safe_crop_box((930, 1130), 10.7, 20.2, 50.9, 70.1, 6) == (4, 14, 56, 76)
+    assert safe_crop_box((930, 1130), -5, -5, 3, 3, 6) == (0, 0, 9, 9)
+    assert safe_crop_box((930, 1130), 1125, 925, 1140, 940, 6) == (1119, 919, 1130, 930)
+    assert safe_crop_box((100, 100), 200, 200, 210, 210, 6) == (99, 99, 100, 100)   # off-frame box: the reference keeps a 1x1 crop
+    assert safe_crop_box((100, 100), 50, 10, 30, 20, 6) is None                      # inverted beyond the pad
