@@ -1,0 +1,89 @@
+"""-m gpu: BASELINE.json's full sizes through size-independent properties (the oracle needs minutes per batch there).
+
+Config 3 (yolov8m 640x640 batch 32), config 4's per-GPU shard (batch 64) and config 5's geometry (1280x1280 batch 16,
+here in f16/f32 - fp8 is not built): determinism, batch independence, kernel-generation equivalence in the exact mode,
+and the invariants of the post-process (sorted scores, boxes inside the frame, class-aware NMS leaves no same-class pair
+above the IoU threshold, oracle post-process on the GPU's own head output gives the identical result)."""
+import numpy as np
+import pytest
+import torch
+
+from manual_yolo_amd.engine import engine_from_weights
+from manual_yolo_amd.synth import synth_frames, synth_meta, synth_state_dict
+from oracle.post_ref import non_max_suppression
+
+pytestmark = pytest.mark.gpu
+NC = 64
+
+
+@pytest.fixture(scope="module")
+def model():
+    sd, meta = synth_state_dict("detect", NC, "m", 0), synth_meta("detect", NC, "m")
+    return {dt: engine_from_weights(sd, meta, dt, 0, bgr_input=False) for dt in ("f32", "f16")}
+
+
+def _iou64(a, b):
+    x1, y1 = np.maximum(a[:, None, 0], b[None, :, 0]), np.maximum(a[:, None, 1], b[None, :, 1])
+    x2, y2 = np.minimum(a[:, None, 2], b[None, :, 2]), np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None, :] - inter + 1e-30)
+
+
+def _check_post_invariants(dets, counts, H, W, iou=0.7, max_det=300):
+    dets, counts = dets.cpu().numpy().astype(np.float64), counts.cpu().numpy()
+    for b in range(dets.shape[0]):
+        n = int(counts[b])
+        assert 0 <= n <= max_det
+        d = dets[b, :n]
+        assert np.all(dets[b, n:] == 0)
+        assert np.all(np.diff(d[:, 4]) <= 0), "scores must be in descending order"
+        assert np.all(d[:, 4] > 0.25) and np.all(d[:, 4] <= 1.0)
+        assert np.all((d[:, 5] >= 0) & (d[:, 5] < NC) & (d[:, 5] == np.floor(d[:, 5])))
+        if n > 1:
+            m = _iou64(d[:, :4], d[:, :4])
+            same = d[:, None, 5] == d[None, :, 5]
+            np.fill_diagonal(m, 0.0)
+            # the reference suppresses on boxes offset by class * 7680 in fp32 (ulp 0.03 px at class 63), so its IoU
+            # differs from this float64 one on the raw boxes by up to ~1e-2 for small boxes; the exact check is the
+            # oracle post-process comparison below
+            assert (m * same).max() <= iou + 1e-2, "two kept boxes of one class overlap above the threshold"
+
+
+@pytest.mark.parametrize("dtype,B,H,W", [("f16", 64, 640, 640), ("f32", 32, 640, 640), ("f16", 16, 1280, 1280)])
+def test_fullsize_determinism_independence_and_nms_invariants(model, dtype, B, H, W):
+    eng = model[dtype]
+    frames = torch.from_numpy(synth_frames(B, H, W, seed=4, kind="noise")).cuda()
+    d1, c1, a1 = eng.detect(frames, conf=0.25, iou=0.7)
+    d2, c2, a2 = eng.detect(frames, conf=0.25, iou=0.7)
+    assert torch.equal(d1, d2) and torch.equal(c1, c2) and torch.equal(a1, a2), "two runs must be bit-identical"
+    _check_post_invariants(d1, c1, H, W)
+    assert int(c1.sum()) > 0
+    # batch independence: frames 5..8 alone == the same frames inside the big batch (other tile lists, chunking, kernels)
+    ds, cs, as_ = eng.detect(frames[5:9].contiguous(), conf=0.25, iou=0.7)
+    assert torch.equal(ds, d1[5:9]) and torch.equal(cs, c1[5:9]) and torch.equal(as_, a1[5:9])
+    # the oracle's post-process on the GPU's own head output reproduces the GPU post-process exactly
+    y = eng.head_raw(frames[:4].contiguous()).cpu().numpy()
+    outs, idxs = non_max_suppression(y, 0.25, 0.7)
+    for b in range(4):
+        n = int(c1[b])
+        assert n == len(idxs[b])
+        assert np.array_equal(a1[b, :n].cpu().numpy(), idxs[b])
+        assert np.array_equal(d1[b, :n].cpu().numpy(), outs[b])
+
+
+def test_fullsize_kernel_generations_agree_bit_exactly_in_f32(model):
+    """Exact mode, batch 64 at 640x640: the default engine (persistent ring + 256x192 tile + two-workgroup kernel +
+    interleaved DMA issue), the warp-specialised kernel and the first LDS-DMA kernel accumulate in the same order,
+    so the head outputs must be bit-identical - a full-size check of every tile schedule against the simplest one."""
+    eng = model["f32"]
+    frames = torch.from_numpy(synth_frames(64, 640, 640, seed=6, kind="blocks")).cuda()
+    ys = {}
+    for impl in (3, 1, 5, 6):
+        eng.set_option("conv_impl", impl)
+        ys[impl] = eng.head_raw(frames).cpu()
+    eng.set_option("conv_impl", 3)
+    for impl in (1, 5, 6):
+        assert torch.equal(ys[3], ys[impl]), f"conv_impl {impl} differs from the default at full size"
+    assert torch.isfinite(ys[3]).all()
