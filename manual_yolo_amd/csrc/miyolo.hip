@@ -21,6 +21,7 @@
 #include "conv_halop.h"
 #include "conv_ws.h"
 #include "conv_dmh.h"
+#include "conv_t2d.h"
 #include "kernels_misc.h"
 #include "nms.h"
 #include "preprocess.h"
@@ -51,6 +52,7 @@ struct miyolo_engine {
   int conv_impl = 3;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for
                             // 3x3 s1 (conv_halo.h); 3: persistent LDS-DMA ring (conv_dmap.h)
   int ncu = 256;
+  int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
   int dbg_op = -1;          // op index whose stamps are wanted
@@ -128,6 +130,17 @@ hipError_t set_dmap_attrs_ks() {
   MIYOLO_DMAP_ATTR(2, 6) MIYOLO_DMAP_ATTR(2, 4) MIYOLO_DMAP_ATTR(2, 3) MIYOLO_DMAP_ATTR(1, 4) MIYOLO_DMAP_ATTR(1, 3)
   MIYOLO_DMAP_ATTR(1, 2) MIYOLO_DMAP_ATTR(1, 1)
 #undef MIYOLO_DMAP_ATTR
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t set_t2d_attrs() {
+  hipError_t e;
+#define MIYOLO_T2D_ATTR(TC)                                                                             \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_t2d_kernel<T, TC>),                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  MIYOLO_T2D_ATTR(1) MIYOLO_T2D_ATTR(2) MIYOLO_T2D_ATTR(3) MIYOLO_T2D_ATTR(4)
+#undef MIYOLO_T2D_ATTR
   return hipSuccess;
 }
 
@@ -327,7 +340,9 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
-      if ((h->conv_impl == 6 || (h->conv_impl == 3 && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
+      if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && t2d_eligible<T>(a))
+        HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
+      else if ((h->conv_impl == 6 || (h->conv_impl == 3 && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
         HIP_TRY(h, launch_conv_dmh<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 5) HIP_TRY(h, launch_conv_ws<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 4 && halop_eligible(a)) HIP_TRY(h, launch_conv_halop<T>(a, s, h->ncu, h->force_wc, h->force_tc));
@@ -400,6 +415,11 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   const int bk = 8 * (h->desc.dtype == MIYOLO_F16 ? 8 : 4);
   const size_t dmh_lds = dmh_lds_bytes() + (size_t)((op.cin * op.ksize * op.ksize + bk - 1) / bk) * 32;
   const bool dmh_auto = h->conv_impl == 3 && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
+  T2dGeom tg; size_t tlds;
+  const bool t2d = (h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && op.ksize == 3 && op.stride == 1 &&
+                   op.n_src == 1 && !op.src[0].upsample &&
+                   t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
+  if (t2d) return 7000 + 300 + 10 + (op.cout + 15) / 16;   // conv_t2d_kernel<T,TC>
   const int impl = (h->conv_impl == 6 || dmh_auto) ? 6 : h->conv_impl == 5 ? 5 : halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
   ConvCfg c = impl == 6 ? pick_dma_cfg(op.cout, M) : impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
               : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
@@ -507,6 +527,8 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_dmap_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_t2d_attrs<float>();
+  if (e == hipSuccess) e = set_t2d_attrs<half_t>();
   if (e == hipSuccess) e = set_dmh_attrs_ks<float, 1>();
   if (e == hipSuccess) e = set_dmh_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dmh_attrs_ks<half_t, 1>();
@@ -541,6 +563,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "force_tc")) { h->force_tc = value; return 0; }
   if (!strcmp(key, "profile")) { h->profile = value; return 0; }
   if (!strcmp(key, "conv_impl")) { h->conv_impl = value; return 0; }
+  if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }
   if (!strcmp(key, "dbg_op")) {
     h->dbg_op = value;

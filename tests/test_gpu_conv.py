@@ -21,7 +21,7 @@ def ref_conv(x, w, b, s, act, res=None):
     return y + res if res is not None else y
 
 
-IMPLS = [0, 1, 2, 3, 4, 5, 6]   # 6: half-size stages, two workgroups per CU (conv_dmh.h); 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+IMPLS = [0, 1, 2, 3, 4, 5, 6, 7]   # 7: narrow 3x3 layers on 16x16 tiles with LDS-resident weights (conv_t2d.h; other shapes fall through to the ring kernel); 6: half-size stages, two workgroups per CU (conv_dmh.h); 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -185,3 +185,39 @@ def test_default_engine_takes_two_workgroup_kernel(dtype, cin, cout, k, H, W, B)
     assert rel_err(y3, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
     if dtype == "f32":
         assert np.array_equal(y3, y1)        # same accumulation order in both kernels: bit-identical in the exact mode
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,B,res", [(48, 48, 32, 32, 3, True), (48, 48, 16, 16, 2, False), (16, 16, 32, 48, 5, True),
+                                                (64, 48, 16, 48, 1, False), (32, 64, 48, 16, 2, True), (8, 24, 16, 16, 70, False),
+                                                (48, 48, 160, 160, 2, True)])
+def test_t2d_kernel_shapes(dtype, cin, cout, H, W, B, res):
+    """conv_t2d.h (conv_impl 7, and the default engine for these shapes): 16x16 tiles, image borders on every side of a
+    tile, one-tile images, more tiles than workgroups (B = 70), channel tails (cout 24), full 160x160 maps; in f32 the
+    result must be bit-identical to the first ring kernel (same accumulation order)."""
+    rng = np.random.default_rng(cin * 131 + cout + H)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype) if res else None
+    y7 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=7)
+    assert rel_err(y7, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
+    y1 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=1)
+    if dtype == "f32":
+        assert np.array_equal(y7, y1)
+    y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=3)      # default engine: same kernel
+    assert np.array_equal(y3, y7)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_t2d_channel_slices(dtype):
+    """input = channels 48..95 of a 96-channel buffer, output into channels 96..143 of a 192-channel buffer."""
+    rng = np.random.default_rng(77)
+    B, H, W, ld, off, cin, cout = 2, 32, 32, 96, 48, 48, 48
+    x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96, impl=7)
+    ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
+    assert rel_err(y[..., 96:96 + cout], ref) < TOL[dtype]
+    assert np.all(y[..., :96] == 7.0) and np.all(y[..., 96 + cout:] == 7.0)
