@@ -18,6 +18,15 @@
 
 namespace miyolo {
 
+// A wave-uniform pointer pinned to SGPRs: under register pressure the compiler may keep a uniform value in VGPRs and then
+// hand an inline-asm "s" operand a VGPR pair (assembler error); readfirstlane of a value already in SGPRs folds away.
+template <typename P>
+__device__ __forceinline__ P* sgpr_ptr(P* p) {
+  const unsigned long long v = (unsigned long long)p;
+  return reinterpret_cast<P*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+
 typedef _Float16 half_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

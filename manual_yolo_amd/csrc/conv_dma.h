@@ -36,8 +36,10 @@ __device__ __forceinline__ void lds_dma16(const v4i_t rsrc, uint32_t lds_addr, u
   // readfirstlane: the address IS wave-uniform, but under SGPR pressure the compiler may keep such a value
   // in a VGPR and then hand the "s" operand a VGPR (assembler error); this pins it to an SGPR.
   const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  const v4i_t rs = {__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]),
+                    __builtin_amdgcn_readfirstlane(rsrc[2]), __builtin_amdgcn_readfirstlane(rsrc[3])};   // folded away when already in SGPRs
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(m0v), "v"(voff), "s"(rsrc) : "memory");
+               :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
 }
 __device__ __forceinline__ v4i_t make_srd(const void* p, uint32_t bytes) {
   const unsigned long long a = (unsigned long long)p;

@@ -23,6 +23,12 @@
 #ifndef MIYOLO_DMAP_INTERLEAVE
 #define MIYOLO_DMAP_INTERLEAVE 1
 #endif
+#ifndef MIYOLO_DMAP_DEFER
+#define MIYOLO_DMAP_DEFER 0
+#endif
+#ifndef MIYOLO_DMAP_EXACT_VMCNT
+#define MIYOLO_DMAP_EXACT_VMCNT 1
+#endif
 
 namespace miyolo {
 
@@ -299,12 +305,61 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     }
   };
 
+  // ---- deferred epilogue (MIYOLO_DMAP_DEFER, OFF: measured 8 % slower on the whole step, same box, back to back):
+  // a finished tile's accumulators move to a second register set and its bias + SiLU + store run one 16x16 piece per K
+  // step of the NEXT tile, right after that step's MFMAs have been issued.  The idea was that the matrix pipe works
+  // through its queue while the VALU does the activations (the epilogue is 7 k of ~36 k cycles per tile with the matrix
+  // pipe idle); in practice every step of every wave gets ~500 VALU cycles longer before its barrier and the step time
+  // grows by about that much - the activations do not hide under this kernel's MFMAs.  Kept for the next round's
+  // 4-wave kernel.  3-slot shapes only, not for residual layers (their loads would drain the DMAs in flight).
+  constexpr bool DEFER_CT = MIYOLO_DMAP_DEFER && NST > 2;
+  constexpr int NP = TC * TPW;                               // pieces per tile
+  f32x4 eacc[DEFER_CT ? TC : 1][DEFER_CT ? TPW : 1];
+  const bool defer = DEFER_CT && a.vec_ok && !a.res;         // wave-uniform, constant for the launch
+  const int ppk = (NP + a.nk - 1) / a.nk;                    // pieces per K step so that a tile's pieces finish within the next tile
+  int e_next = NP, e_m0 = 0, e_n0 = 0;                       // next piece to run (NP = nothing pending)
+  auto piece_ij = [&](auto ic, auto jc) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+    if constexpr (DEFER_CT) {
+      const int nt = __builtin_amdgcn_readfirstlane(e_n0 + (wc * TC + i) * 16);
+      const int n = nt + fq * 4;
+      v4i_t s0, s1, s2, s3;
+      const float* bp = sgpr_ptr(a.bias + nt);
+      asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
+                   "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+      const int m = __builtin_amdgcn_readfirstlane(e_m0) + (wp * TPW + j) * 16 + frow;
+      const v4ie_t zr = {0, 0, 0, 0};
+      if (a.out_f32) epilogue_fast<T, true>(a, rdst, m, n, eacc[i][j], bv, zr);
+      else epilogue_fast<T, false>(a, rdst, m, n, eacc[i][j], bv, zr);
+    }
+  };
+  auto run_piece = [&](int p) __attribute__((always_inline)) {   // p is wave-uniform: a jump over NP small blocks; must inline (captures live in registers)
+    if constexpr (DEFER_CT) {
+#define MIYOLO_PIECE(I, J) case (I) * TPW + (J): if constexpr ((I) < TC && (J) < TPW) piece_ij(std::integral_constant<int, (I)>{}, std::integral_constant<int, (J)>{}); break;
+#define MIYOLO_PIECE_ROW(I) MIYOLO_PIECE(I, 0) MIYOLO_PIECE(I, 1) MIYOLO_PIECE(I, 2) MIYOLO_PIECE(I, 3)
+      if constexpr (TPW == 4) {
+        switch (p) { MIYOLO_PIECE_ROW(0) MIYOLO_PIECE_ROW(1) MIYOLO_PIECE_ROW(2) MIYOLO_PIECE_ROW(3) default: break; }
+      } else {                                               // TPW == 2
+        switch (p) { MIYOLO_PIECE(0, 0) MIYOLO_PIECE(0, 1) MIYOLO_PIECE(1, 0) MIYOLO_PIECE(1, 1) MIYOLO_PIECE(2, 0) MIYOLO_PIECE(2, 1)
+                     MIYOLO_PIECE(3, 0) MIYOLO_PIECE(3, 1) default: break; }
+      }
+#undef MIYOLO_PIECE_ROW
+#undef MIYOLO_PIECE
+    }
+  };
+
   // ---- stream: prologue issues two stages, then one barrier + one issue + one compute per step
   setup_tile(d_tile);
   issue_next();
   if (NST > 2 && total_steps > 1) issue_next();
 
   int c_tile = first, c_ks = 0, c_slot = 0;
+  int v_stores = 0;                      // vector stores issued since the last DMA of the youngest stage (wave-uniform)
 #if MIYOLO_ABLATE
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, acc_epi = 0, t_begin = 0;
   STAMP(t_begin);
@@ -312,11 +367,20 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   for (int c = 0; c < total_steps; ++c) {
     STAMP(t0);
     if (NST > 2 && c + 1 < total_steps) {      // one younger stage may stay in flight
-      if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      // vmcnt counts loads, stores and LDS-DMAs together, in issue order: what may stay outstanding is the youngest
+      // stage's NI DMAs PLUS the epilogue stores issued after them (v_stores).  Waiting for fewer would wait for those
+      // DMAs themselves - a full DMA latency per step (measured: 2.3x slower with one store per step unaccounted).
+#define MIYOLO_WAIT(K) case (K): asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NI + (K)) : "memory"); break;
+      switch (MIYOLO_DMAP_EXACT_VMCNT ? v_stores : 0) {
+        MIYOLO_WAIT(0) MIYOLO_WAIT(1) MIYOLO_WAIT(2) MIYOLO_WAIT(3) MIYOLO_WAIT(4) MIYOLO_WAIT(5) MIYOLO_WAIT(6) MIYOLO_WAIT(7) MIYOLO_WAIT(8)
+        MIYOLO_WAIT(12) MIYOLO_WAIT(16)
+        default: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NI) : "memory"); break;   // uncounted: conservative
+      }
+#undef MIYOLO_WAIT
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    v_stores = 0;
     STAMP(t1);
     // (Tried and rejected, profiles/r01_conv_stamps.md: letting waves 4-7 run MFMAs first and DMAs
     // second, so that the vector-memory path and the matrix pipe overlap across SIMD partners,
@@ -329,6 +393,9 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       if (d_issued < total_steps) issue_next();
       STAMP(t2);
       compute(c_slot);
+    }
+    if constexpr (DEFER_CT) {                                  // pieces of the previous tile, in the shadow of this step's MFMAs
+      for (int r = 0; r < ppk && e_next < NP; ++r, ++e_next) { run_piece(e_next); ++v_stores; }
     }
     STAMP(t3);
 #if MIYOLO_ABLATE
@@ -350,7 +417,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
           const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + i) * 16);
           const int n = nt + fq * 4;
           v4i_t s0, s1, s2, s3;            // 16 consecutive biases of this 16-channel tile, in SGPRs
-          const float* bp = bias + nt;
+          const float* bp = sgpr_ptr(bias + nt);
           asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
                        "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
                        : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
@@ -374,8 +441,17 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
           }
         }
       };
-      if (a.vec_ok) {
+      if (defer) {
+        if constexpr (DEFER_CT) {
+#pragma unroll
+          for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) { eacc[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          e_m0 = m0; e_n0 = n0; e_next = 0;
+        }
+      } else if (a.vec_ok) {
         if (a.out_f32) run_epilogue(std::true_type{}); else run_epilogue(std::false_type{});
+        v_stores += (ABL(8) ? 0 : NP);          // one vector store per 16x16 piece (its residual loads have been consumed)
       } else {                                   // odd channel counts (e.g. nc = 13): scalar path
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -402,6 +478,9 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       acc_epi += t4 - t3;
 #endif
     }
+  }
+  if constexpr (DEFER_CT) {
+    for (; e_next < NP; ++e_next) run_piece(e_next);           // the last tile's pieces
   }
 #if MIYOLO_ABLATE
   if (a.dbg && lane == 0) {          // per wave: total, wait, issue, compute, epilogue cycles + steps

@@ -17,7 +17,8 @@ import torch
 from .arch import OP_DECODE, Op, Program, View, build_program
 from .weights import K_ALIGN, build_weight_tensors
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmiyolo.so")
+# MIYOLO_LIB: an alternative build of the same ABI (A/B timing of kernel variants on one box); still no CPU fallback
+_LIB_PATH = os.environ.get("MIYOLO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmiyolo.so")
 DT_CODE = {"f32": 0, "f16": 1}
 
 
