@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--workload", default="detect", choices=["detect", "classify"])
     ap.add_argument("--chunk", type=int, default=0, help="images per engine pass (0 = auto)")
     ap.add_argument("--conv-impl", type=int, default=-1, help="0 register-staged conv, 1 LDS-DMA ring, 2 ring + halo kernel, 3 persistent ring, 4 persistent halo, 5 warp-specialised, 6 half-size stages x 2 workgroups per CU (default: engine default)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (miyolo_set_option), repeatable: A/B timing of kernel choices")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (wrong results): see common.h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -107,6 +108,9 @@ def main():
         eng.set_option("conv_impl", args.conv_impl)
     if args.ablate:
         eng.set_option("ablate", args.ablate)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     frames_np = synth_frames(B, H, W, seed=1 + rank)
     frames = torch.from_numpy(frames_np).to(dev)
     max_det = 300

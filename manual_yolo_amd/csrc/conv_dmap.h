@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     // second, so that the vector-memory path and the matrix pipe overlap across SIMD partners,
     // made every layer 20-25 % slower - the LDS-DMA writes and the partner's ds_reads/MFMA issue
     // interfere.)
-    if constexpr (MIYOLO_DMAP_INTERLEAVE && NST > 2) {      // measured: -3...-9 % on the 3-slot 3x3 shapes, +4 % on the 2-slot 256x192 tile
+    if constexpr (MIYOLO_DMAP_INTERLEAVE && (NST > 2 || MIYOLO_DMAP_INTERLEAVE > 1)) {      // measured: -3...-9 % on the 3-slot 3x3 shapes, +4 % on the 2-slot 256x192 tile
       STAMP(t2);
       compute_issue(c_slot, d_issued < total_steps);
     } else {
@@ -526,15 +526,31 @@ inline hipError_t launch_dmap_ks(const ConvArgs& a, ConvCfg c, hipStream_t s, in
   return launch_dmap_cfg<T, KS, 1, 1>(a, s, ncu);
 }
 
-// Tile choice for the persistent kernel: as pick_dma_cfg, plus the 256 x 192 tile (8 waves of 64 x 96:
-// 30 % fewer LDS fragment bytes and 37 % fewer filled bytes per FLOP than 64 x 48 wave tiles) for layers with
-// exactly 192 output channels and at least one tile per CU.  Measured (profiles/r01_tile_256x192.md): +12...16 %
-// on those layers (the activation tile is fetched once instead of twice), but -8...-13 % on the 384/576-channel
-// layers, where it halves the tile count (coarser tail) and runs on a 2-slot ring - so not used there.
+// Tile choice for the persistent kernel.  Cost model fitted to same-box per-layer timings of every forced shape
+// (profiles/r01_tile_choice.md): a launch takes  rounds x (BN + c0)  with  rounds = ceil(tiles / CUs)  - what decides
+// between shapes is mostly how the tile count divides by the CU count (576 channels at 20x20: 600 tiles of 96 channels
+// are three rounds, 500 tiles of 128 are two: -13...-19 %), then the channel padding, with a small penalty for the
+// 32-pixel wave tiles of the 8x1 layouts.  The 256 x 192 tile (8 waves of 64 x 96: 30 % fewer LDS fragment bytes and
+// 37 % fewer filled bytes per FLOP) competes under the same rule; it needs at least one tile per CU.
+inline double dmap_cost(int cout, long M, int ncu, ConvCfg c) {
+  const int bn = c.wc * c.tc * 16;
+  const long mbk = (M + DMA_BM - 1) / DMA_BM, nb = (cout + bn - 1) / bn, tiles = mbk * nb;
+  const long rounds = (tiles + ncu - 1) / ncu;
+  double cost = (double)rounds * (bn + 40.0);
+  if (c.wc == 1) cost *= 1.05;
+  return cost;
+}
 inline ConvCfg pick_dmap_cfg(int cout, long M, int ncu) {
+  static const ConvCfg cands[] = {{2, 6}, {2, 4}, {2, 3}, {1, 4}, {1, 3}, {1, 2}, {1, 1}};
   const long mbk = (M + DMA_BM - 1) / DMA_BM;
-  if (cout == 192 && mbk >= ncu) return {2, 6};
-  return pick_dma_cfg(cout, M);
+  ConvCfg best = {1, 1};
+  double best_cost = 1e30;
+  for (const ConvCfg& c : cands) {
+    if (c.tc == 6 && (mbk * ((cout + 191) / 192) < ncu || cout % 192)) continue;
+    const double cost = dmap_cost(cout, M, ncu, c);
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
 }
 
 template <typename T>

@@ -289,10 +289,13 @@ inline bool dmh_eligible(const ConvArgs& a) { return dmh_lds_bytes() + (size_t)a
 // faster on exactly these layers (20x20 288-channel bottlenecks, the 40x40 64-channel box branch), 12-40 % slower
 // everywhere else, where half-size stages only add barriers.
 inline bool dmh_preferred_shape(int cout, long M, int ncu) {
-  const ConvCfg c = pick_dmap_cfg(cout, M, ncu);
-  if (c.tc > 4) return false;
-  const long mbk = (M + DMA_BM - 1) / DMA_BM, nb = (cout + c.wc * c.tc * 16 - 1) / (c.wc * c.tc * 16);
-  return mbk * nb > ncu && mbk * nb <= 2L * ncu;
+  const ConvCfg cd = pick_dma_cfg(cout, M);                    // the shape conv_dmh would run
+  const int bn = cd.wc * cd.tc * 16;
+  const long mbk = (M + DMA_BM - 1) / DMA_BM, nb = (cout + bn - 1) / bn, tiles = mbk * nb;
+  if (tiles <= ncu || tiles > 2L * ncu) return false;
+  // two workgroups share a CU: each tile takes ~1.7x as long (same-box timings), but all tiles run in one round
+  const double dmh_cost = 1.7 * (bn + 40.0) * (cd.wc == 1 ? 1.05 : 1.0);
+  return dmh_cost < dmap_cost(cout, M, ncu, pick_dmap_cfg(cout, M, ncu));
 }
 inline bool dmh_preferred(const ConvArgs& a, int ncu) { return dmh_preferred_shape(a.cout, a.M, ncu); }
 

@@ -52,6 +52,7 @@ struct miyolo_engine {
   int conv_impl = 3;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for
                             // 3x3 s1 (conv_halo.h); 3: persistent LDS-DMA ring (conv_dmap.h)
   int ncu = 256;
+  int dmh_auto = 1;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h)
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
@@ -342,7 +343,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
       if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && t2d_eligible<T>(a))
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
-      else if ((h->conv_impl == 6 || (h->conv_impl == 3 && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
+      else if ((h->conv_impl == 6 || (h->conv_impl == 3 && h->dmh_auto && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
         HIP_TRY(h, launch_conv_dmh<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 5) HIP_TRY(h, launch_conv_ws<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 4 && halop_eligible(a)) HIP_TRY(h, launch_conv_halop<T>(a, s, h->ncu, h->force_wc, h->force_tc));
@@ -414,7 +415,7 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
                      (p.W / ob.down) <= 95 && op.cout % 4 == 0;
   const int bk = 8 * (h->desc.dtype == MIYOLO_F16 ? 8 : 4);
   const size_t dmh_lds = dmh_lds_bytes() + (size_t)((op.cin * op.ksize * op.ksize + bk - 1) / bk) * 32;
-  const bool dmh_auto = h->conv_impl == 3 && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
+  const bool dmh_auto = h->conv_impl == 3 && h->dmh_auto && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
   T2dGeom tg; size_t tlds;
   const bool t2d = (h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && op.ksize == 3 && op.stride == 1 &&
                    op.n_src == 1 && !op.src[0].upsample &&
@@ -564,6 +565,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "profile")) { h->profile = value; return 0; }
   if (!strcmp(key, "conv_impl")) { h->conv_impl = value; return 0; }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
+  if (!strcmp(key, "dmh_auto")) { h->dmh_auto = value; return 0; }
   if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }
   if (!strcmp(key, "dbg_op")) {
     h->dbg_op = value;
