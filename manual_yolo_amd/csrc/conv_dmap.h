@@ -26,6 +26,9 @@
 #ifndef MIYOLO_DMAP_DEFER
 #define MIYOLO_DMAP_DEFER 0
 #endif
+#ifndef MIYOLO_DMAP_BALANCED_GRID
+#define MIYOLO_DMAP_BALANCED_GRID 1
+#endif
 #ifndef MIYOLO_DMAP_EXACT_VMCNT
 #define MIYOLO_DMAP_EXACT_VMCNT 1
 #endif
@@ -510,6 +513,14 @@ inline hipError_t launch_dmap_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;                  // K > ~32k: not a YOLO layer
   const long mbk = ((long)a.M + DMA_BM - 1) / DMA_BM, nb = (a.cout + BN - 1) / BN;
   long grid = std::min<long>(mbk * nb, ncu);
+#if MIYOLO_DMAP_BALANCED_GRID
+  {                                      // same number of rounds, but every workgroup gets the same number of tiles: the CUs
+                                         // that would idle through the last round stay idle throughout and the others see less
+                                         // contention on the L2 -> LDS path (measured +3.3 % on the whole step, same box)
+    const long rounds = (mbk * nb + ncu - 1) / ncu;
+    grid = std::min<long>((mbk * nb + rounds - 1) / rounds, ncu);
+  }
+#endif
   grid = (grid + 7) / 8 * 8;             // the tile dealing assumes a multiple of 8
   hipLaunchKernelGGL((conv_dmap_kernel<T, KS, WC, TC>), dim3((unsigned)grid), dim3(512), lds, s, a);
   return hipGetLastError();

@@ -266,6 +266,12 @@ inline hipError_t launch_dmh_cfg(const ConvArgs& a, hipStream_t s, int ncu) {
   if (lds > 80 * 1024) return hipErrorInvalidValue;                   // two workgroups must fit a CU's 160 KiB
   const long mbk = ((long)a.M + DMA_BM - 1) / DMA_BM, nb = (a.cout + BN - 1) / BN;
   long grid = std::min<long>(mbk * nb, 2L * ncu);
+#if MIYOLO_DMAP_BALANCED_GRID
+  {
+    const long rounds = (mbk * nb + 2L * ncu - 1) / (2L * ncu);
+    grid = std::min<long>((mbk * nb + rounds - 1) / rounds, 2L * ncu);
+  }
+#endif
   grid = (grid + 7) / 8 * 8;
   hipLaunchKernelGGL((conv_dmh_kernel<T, KS, WC, TC>), dim3((unsigned)grid), dim3(512), lds, s, a);
   return hipGetLastError();
