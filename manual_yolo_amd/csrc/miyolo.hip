@@ -52,7 +52,8 @@ struct miyolo_engine {
   int conv_impl = 3;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for
                             // 3x3 s1 (conv_halo.h); 3: persistent LDS-DMA ring (conv_dmap.h)
   int ncu = 256;
-  int dmh_auto = 1;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h)
+  int dmh_auto = 0;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h); off since the
+                            // balanced grids: +0.2 % without it (same-box A/B), it won only by removing a half-empty round
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
@@ -566,6 +567,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "conv_impl")) { h->conv_impl = value; return 0; }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "dmh_auto")) { h->dmh_auto = value; return 0; }
+  if (!strcmp(key, "ncu")) { if (value < 8 || value > 1024) return fail(h, MIYOLO_ERR_ARG, "ncu out of range"); h->ncu = value; return 0; }   // persistent-grid width (A/B)
   if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }
   if (!strcmp(key, "dbg_op")) {
     h->dbg_op = value;

@@ -172,19 +172,21 @@ def test_ws_2x2_consumer_grid(dtype, k, s, cin, cout, H, W, B, res):
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("cin,cout,k,H,W,B", [(96, 96, 3, 40, 40, 48), (192, 64, 1, 40, 40, 64)])
-def test_default_engine_takes_two_workgroup_kernel(dtype, cin, cout, k, H, W, B):
-    """conv_impl 3 (the default) hands launches with more than one and at most two 256-pixel tiles per CU to
-    conv_dmh.h (dmh_preferred_shape): 300 / 400 tiles here; full-size persistent grid, residual, every tail."""
+def test_one_to_two_tiles_per_cu(dtype, cin, cout, k, H, W, B):
+    """Launches with more than one and at most two 256-pixel tiles per CU (300 / 400 tiles): the default engine's
+    balanced persistent grid (150 / 200 workgroups, two tiles each) and, with the `dmh_auto` option, the two-workgroup
+    kernel conv_dmh.h; residual, every tail."""
     rng = np.random.default_rng(5)
     x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
     w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
     res = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype)
     y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=3)
+    y6 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=6)
     y1 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=1)
     assert rel_err(y3, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
     if dtype == "f32":
-        assert np.array_equal(y3, y1)        # same accumulation order in both kernels: bit-identical in the exact mode
+        assert np.array_equal(y3, y1) and np.array_equal(y6, y1)   # same accumulation order in all kernels: bit-identical in the exact mode
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])

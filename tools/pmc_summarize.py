@@ -10,7 +10,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(conv_halop_kernel|conv_halo_kernel|conv_dmap_kernel|conv_dmh_kernel|conv_ws_kernel|conv_dma_kernel|conv_igemm_kernel|stem_kernel|maxpool5_kernel|decode_kernel|"
+    m = re.search(r"(conv_t2d_kernel|conv_halop_kernel|conv_halo_kernel|conv_dmap_kernel|conv_dmh_kernel|conv_ws_kernel|conv_dma_kernel|conv_igemm_kernel|stem_kernel|maxpool5_kernel|decode_kernel|"
                   r"nms_sort_greedy_kernel|nms_prefilter_kernel|cls_head_kernel)", name)
     if not m:
         return name[:40]
