@@ -52,6 +52,10 @@ struct miyolo_engine {
   int conv_impl = 3;        // 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for
                             // 3x3 s1 (conv_halo.h); 3: persistent LDS-DMA ring (conv_dmap.h)
   int ncu = 256;
+  int graph = 0;            // 1: capture the launches of a classify/detect call into a hipGraph and replay it while the
+                            // call's shape, thresholds, stream and pointers stay the same (launch-bound classifier path)
+  struct GraphRec { unsigned char key[160]; size_t klen; hipGraph_t g; hipGraphExec_t ex; };
+  std::vector<GraphRec> graphs;
   int dmh_auto = 0;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h); off since the
                             // balanced grids: +0.2 % without it (same-box A/B), it won only by removing a half-empty round
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
@@ -479,6 +483,40 @@ int prepare(miyolo_engine* h, int B, int H, int W, size_t ws_bytes, void* ws) {
   return 0;
 }
 
+// hipGraph replay of one entry point's launch sequence (option "graph").  Everything the launches bake in is part of the
+// key: entry, shape, thresholds, stream, every pointer; any option change drops the graphs.  A changed key re-captures
+// (at most 8 graphs are kept).  Capture needs a non-default stream; on the null stream, or while profiling, the call
+// runs directly.
+template <class F>
+int with_graph(miyolo_engine* h, hipStream_t s, const void* key, size_t klen, F&& body) {
+  if (!h->graph || h->profile || s == nullptr || klen > sizeof(miyolo_engine::GraphRec::key)) return body();
+  for (auto& r : h->graphs)
+    if (r.klen == klen && !memcmp(r.key, key, klen)) { HIP_TRY(h, hipGraphLaunch(r.ex, s)); return 0; }
+  HIP_TRY(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess || !g) return fail(h, MIYOLO_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t ex = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e2 != hipSuccess) { (void)hipGraphDestroy(g); return fail(h, MIYOLO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+  if (h->graphs.size() >= 8) {
+    (void)hipGraphExecDestroy(h->graphs.front().ex); (void)hipGraphDestroy(h->graphs.front().g);
+    h->graphs.erase(h->graphs.begin());
+  }
+  miyolo_engine::GraphRec r;
+  memset(&r, 0, sizeof(r));
+  memcpy(r.key, key, klen); r.klen = klen; r.g = g; r.ex = ex;
+  h->graphs.push_back(r);
+  HIP_TRY(h, hipGraphLaunch(ex, s));
+  return 0;
+}
+void drop_graphs(miyolo_engine* h) {
+  for (auto& r : h->graphs) { (void)hipGraphExecDestroy(r.ex); (void)hipGraphDestroy(r.g); }
+  h->graphs.clear();
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -554,12 +592,14 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   return 0;
 }
 
-void miyolo_destroy(miyolo_handle h) { delete h; }
+void miyolo_destroy(miyolo_handle h) { if (h) drop_graphs(h); delete h; }
 
 const char* miyolo_last_error(miyolo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!h || !key) return MIYOLO_ERR_ARG;
+  drop_graphs(h);                                    // every option can change which kernels a call launches
+  if (!strcmp(key, "graph")) { h->graph = value; return 0; }
   if (!strcmp(key, "max_chunk")) { h->max_chunk = value; h->plan = Plan(); return 0; }
   if (!strcmp(key, "force_wc")) { h->force_wc = value; return 0; }
   if (!strcmp(key, "force_tc")) { h->force_tc = value; return 0; }
@@ -602,15 +642,19 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Plan& p = h->plan;
   const float* y = reinterpret_cast<const float*>(static_cast<unsigned char*>(workspace) + p.y_off);
-  for (int b0 = 0; b0 < B; b0 += p.B) {
-    Plan pc = p;
-    pc.B = std::min(p.B, B - b0);
-    if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s)) return rc;
-    if (int rc = run_nms(h, pc, y, pc.B, p.A, conf, iou, agnostic, max_det, scale ? scale + (size_t)b0 * 5 : nullptr,
-                         out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
-                         out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, s)) return rc;
-  }
-  return 0;
+  struct { int entry, B, H, W, agnostic, max_det; float conf, iou; const void* in; const void* scale; void* d; void* c; void* a; void* ws; hipStream_t s; }
+      key = {1, B, H, W, agnostic, max_det, conf, iou, in, scale, out_dets, out_counts, out_anchor, workspace, s};
+  return with_graph(h, s, &key, sizeof(key), [&]() -> int {
+    for (int b0 = 0; b0 < B; b0 += p.B) {
+      Plan pc = p;
+      pc.B = std::min(p.B, B - b0);
+      if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s)) return rc;
+      if (int rc = run_nms(h, pc, y, pc.B, p.A, conf, iou, agnostic, max_det, scale ? scale + (size_t)b0 * 5 : nullptr,
+                           out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
+                           out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, s)) return rc;
+    }
+    return 0;
+  });
 }
 
 int miyolo_head_raw(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* y_out, void* workspace,
@@ -666,13 +710,16 @@ int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Plan& p = h->plan;
   const int nc = h->desc.nc;
-  for (int b0 = 0; b0 < B; b0 += p.B) {
-    Plan pc = p;
-    pc.B = std::min(p.B, B - b0);
-    if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace,
-                         logits ? logits + (size_t)b0 * nc : nullptr, probs ? probs + (size_t)b0 * nc : nullptr, s)) return rc;
-  }
-  return 0;
+  struct { int entry, B, H, W; const void* in; void* lg; void* pr; void* ws; hipStream_t s; } key = {2, B, H, W, in, logits, probs, workspace, s};
+  return with_graph(h, s, &key, sizeof(key), [&]() -> int {
+    for (int b0 = 0; b0 < B; b0 += p.B) {
+      Plan pc = p;
+      pc.B = std::min(p.B, B - b0);
+      if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace,
+                           logits ? logits + (size_t)b0 * nc : nullptr, probs ? probs + (size_t)b0 * nc : nullptr, s)) return rc;
+    }
+    return 0;
+  });
 }
 
 int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int B, int H, int W, void* workspace,

@@ -176,6 +176,21 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self.lib.miyolo_set_option(self.h, key.encode(), int(value)), "miyolo_set_option")
+        if key == "graph":
+            # hipGraph replay (library option "graph"): capture needs a non-default stream, and the replayed launches
+            # write to the buffers of the captured call - so graph mode owns a side stream and per-shape output buffers
+            self._graph = bool(value)
+            self._gstream = torch.cuda.Stream(self.device) if value else None
+            self._gout = {}
+
+    def _graph_call(self, fn):
+        """Run fn() on the graph side stream, ordered after / before the caller's current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        self._gstream.wait_stream(cur)
+        with torch.cuda.stream(self._gstream):
+            r = fn()
+        cur.wait_stream(self._gstream)
+        return r
 
     def workspace(self, B: int, H: int, W: int) -> torch.Tensor:
         need = self.lib.miyolo_workspace_bytes(self.h, B, H, W)
@@ -213,10 +228,14 @@ class Engine:
             anchor = torch.empty((B, max_det), dtype=torch.int32, device=self.device) if want_anchor else None
         else:
             dets, counts, anchor = out
-        rc = self.lib.miyolo_detect(self.h, x.data_ptr(), B, H, W, float(np.float32(conf)), iou_threshold_f32(iou),
-                                    int(agnostic), max_det, _ptr(scale), dets.data_ptr(), counts.data_ptr(),
-                                    _ptr(anchor), ws.data_ptr(), ws.numel(), self._stream())
-        self._check(rc, "miyolo_detect")
+        call = lambda: self._check(
+            self.lib.miyolo_detect(self.h, x.data_ptr(), B, H, W, float(np.float32(conf)), iou_threshold_f32(iou), int(agnostic), max_det,
+                                   _ptr(scale), dets.data_ptr(), counts.data_ptr(), _ptr(anchor), ws.data_ptr(), ws.numel(), self._stream()),
+            "miyolo_detect")
+        if getattr(self, "_graph", False) and out is not None:      # replay only makes sense with caller-owned, reused outputs
+            self._graph_call(call)
+        else:
+            call()
         return dets, counts, anchor
 
     def head_raw(self, frames: torch.Tensor) -> torch.Tensor:
@@ -242,8 +261,19 @@ class Engine:
         return dets, counts, anchor
 
     def classify(self, frames: torch.Tensor):
+        """uint8 [B,H,W,3] -> (logits, probs) [B,nc] f32.  In graph mode the returned tensors are the engine's own
+        per-shape buffers: valid until the next call with the same shape."""
         x, B, H, W = self._in(frames)
         ws = self.workspace(B, H, W)
+        if getattr(self, "_graph", False):
+            if ("c", B, H, W) not in self._gout:
+                self._gout[("c", B, H, W)] = (torch.empty((B, self.nc), dtype=torch.float32, device=self.device),
+                                              torch.empty((B, self.nc), dtype=torch.float32, device=self.device))
+            logits, probs = self._gout[("c", B, H, W)]
+            self._graph_call(lambda: self._check(
+                self.lib.miyolo_classify(self.h, x.data_ptr(), B, H, W, logits.data_ptr(), probs.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         self._stream()), "miyolo_classify"))
+            return logits, probs
         logits = torch.empty((B, self.nc), dtype=torch.float32, device=self.device)
         probs = torch.empty((B, self.nc), dtype=torch.float32, device=self.device)
         self._check(self.lib.miyolo_classify(self.h, x.data_ptr(), B, H, W, logits.data_ptr(), probs.data_ptr(),

@@ -90,3 +90,29 @@ def test_bad_shapes_are_errors(engines):
         eng.classify(torch.zeros((1, 64, 64, 4), dtype=torch.uint8).cuda())
     with pytest.raises(MiyoloError):
         eng.detect(torch.zeros((1, 64, 64, 3), dtype=torch.uint8).cuda())          # wrong task
+
+
+def test_hip_graph_replay_matches_direct_launches(rank_bundles, rank_valid):
+    """Option "graph": the classifier's 27 launches captured once and replayed (the launch-bound B=256 config).
+    Same results as direct launches, across repeated calls, a changed input buffer (re-capture) and a changed batch."""
+    from manual_yolo_amd.engine import engine_from_weights
+    sd, meta = rank_bundles["best"]
+    eng = engine_from_weights(sd, meta, "f32", 0, bgr_input=False)
+    x = torch.from_numpy(np.tile(rank_valid["pre_u8"], (4, 1, 1, 1))[:256]).cuda()
+    l0, p0 = eng.classify(x)
+    l0, p0 = l0.clone(), p0.clone()
+    eng.set_option("graph", 1)
+    for _ in range(3):
+        l1, p1 = eng.classify(x)
+        torch.cuda.synchronize()
+        assert torch.equal(l1, l0) and torch.equal(p1, p0)
+    x2 = x.flip(0).contiguous()                       # other pointer, other content: must re-capture, not replay stale pointers
+    l2, _ = eng.classify(x2)
+    torch.cuda.synchronize()
+    assert torch.equal(l2, l0.flip(0))
+    l3, _ = eng.classify(x[:7].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(l3, l0[:7])
+    eng.set_option("graph", 0)
+    l4, _ = eng.classify(x)
+    assert torch.equal(l4, l0)
