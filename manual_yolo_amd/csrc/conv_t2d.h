@@ -141,6 +141,23 @@ __global__ __launch_bounds__(512) void conv_t2d_kernel(const ConvArgs a, const T
     if (t > 0) asm volatile("s_barrier" ::: "memory");      // tile t landed (every wave waited its DMAs before its epilogue) and
                                                             // buffer buf^1 is no longer read (everyone finished the MFMAs of t-1)
     if (t + 1 < my_tiles) issue_tile(tile + G, buf ^ 1);
+    int b, ty, tx;
+    tile_coords(tile, &b, &ty, &tx);
+    // residual operand of this tile: loaded NOW, consumed after the K loop (its latency hides under the MFMAs; the
+    // vmcnt(0) below covers these loads together with the DMAs)
+    v4ie_t rv[TC][2];
+    if (a.res) {
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          rv[i][j] = epilogue_res_load<T>(a, rres, (b * a.Hout + ty * 16 + 2 * wave + j) * a.Wout + tx * 16 + frow, i * 16 + fq * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rv[i][j] = (v4ie_t){0, 0, 0, 0};
+    }
     const unsigned char* xs = smem + x_base + buf * g.xbuf_bytes;
 #pragma unroll 2
     for (int kg = 0; kg < g.ng; ++kg) {
@@ -158,8 +175,6 @@ __global__ __launch_bounds__(512) void conv_t2d_kernel(const ConvArgs a, const T
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's part of tile t+1 has landed (it had the whole K loop)
 
     // ---- epilogue of tile t
-    int b, ty, tx;
-    tile_coords(tile, &b, &ty, &tx);
     const float* __restrict__ bias = a.bias;
     auto run_epilogue = [&](auto outf32_tag) {
       constexpr bool OUTF32 = decltype(outf32_tag)::value;
@@ -176,16 +191,10 @@ __global__ __launch_bounds__(512) void conv_t2d_kernel(const ConvArgs a, const T
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
-        v4ie_t rv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int m = (b * a.Hout + ty * 16 + 2 * wave + j) * a.Wout + tx * 16 + frow;
-          rv[j] = a.res ? epilogue_res_load<T>(a, rres, m, n) : (v4ie_t){0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int m = (b * a.Hout + ty * 16 + 2 * wave + j) * a.Wout + tx * 16 + frow;
-          epilogue_fast<T, OUTF32>(a, rdst, m, n, acc[i][j], bv, rv[j]);
+          epilogue_fast<T, OUTF32>(a, rdst, m, n, acc[i][j], bv, rv[i][j]);
           acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
