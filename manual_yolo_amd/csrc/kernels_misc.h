@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[tc][r] = a.bias[tc * 16 + q * 4 + r];
 
+  const int W3 = a.W * 3;
+  const int startq = (q < 3) ? q * W3 : 8, stepq = (q < 3) ? 1 : W3;
+  const uint32_t m_always = (q < 3) ? 0u : 0xF8u, m_top = (q < 3) ? (q == 0 ? 0xFFu : 0u) : 1u, m_left = (q < 3) ? 7u : 0u;
+
   for (long tile = wave_global; tile < ntiles; tile += nwaves) {
     const long m = tile * 16 + frow;
     const bool vm = m < total;
@@ -61,14 +65,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     const int wo = (int)rem - ho * a.Wo;
     const int wi0 = 2 * wo - 1, hi0 = 2 * ho - 1;
     float x[8];
+    // byte j of lane group q (see pack_stem_weight): q<3: row hi0+q, bytes j of the 9-byte run starting at column wi0;
+    // q==3: rows hi0+j (j<3), byte 8.  Offsets are rb + startq + j*stepq with per-lane constants; only the top row
+    // (ho == 0) and the left column (wo == 0) can fall outside the image (even H, W; stride 2), as per-lane bit masks.
+    const int rb = ((b * a.H + hi0) * a.W + wi0) * 3;
+    const uint32_t inval = (vm ? m_always : 0xFFu) | (ho == 0 ? m_top : 0u) | (wo == 0 ? m_left : 0u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      // q<3: row hi0+q, byte j of the 9-byte run;  q==3: row hi0+j, byte 8 (j<3)
-      const int hi = (q < 3) ? hi0 + q : hi0 + j;
-      const int bo = (q < 3) ? j : 8;
-      const int wi = wi0 + bo / 3;
-      const bool ok = vm && (q < 3 || j < 3) && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      const uint32_t off = ok ? (uint32_t)(((b * a.H + hi) * a.W + wi0) * 3 + bo) : 0x80000000u;   // < 2^31: checked by the host
+      const uint32_t off = (uint32_t)(rb + startq + j * stepq) | (((inval >> j) & 1u) << 31);
       const uint32_t u = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
       x[j] = a.exact ? (float)u / 255.0f : (float)u * (1.0f / 255.0f);   // f16: rounded to half right after
     }
