@@ -538,7 +538,7 @@ inline hipError_t launch_dmap_ks(const ConvArgs& a, ConvCfg c, hipStream_t s, in
 }
 
 // Tile choice for the persistent kernel.  Cost model fitted to same-box per-layer timings of every forced shape
-// (profiles/r01_tile_choice.md): a launch takes  rounds x (BN + c0)  with  rounds = ceil(tiles / CUs)  - what decides
+// (profiles/r01_tile_choice.md): a launch takes  rounds x (BN + c0)  with  rounds = ceil(tiles / CUs), c0 = 100 (15: -0.6 %, 40: -0.4 %, 80-200: equal, same-box)  - what decides
 // between shapes is mostly how the tile count divides by the CU count (576 channels at 20x20: 600 tiles of 96 channels
 // are three rounds, 500 tiles of 128 are two: -13...-19 %), then the channel padding, with a small penalty for the
 // 32-pixel wave tiles of the 8x1 layouts.  The 256 x 192 tile (8 waves of 64 x 96: 30 % fewer LDS fragment bytes and
@@ -547,7 +547,10 @@ inline double dmap_cost(int cout, long M, int ncu, ConvCfg c) {
   const int bn = c.wc * c.tc * 16;
   const long mbk = (M + DMA_BM - 1) / DMA_BM, nb = (cout + bn - 1) / bn, tiles = mbk * nb;
   const long rounds = (tiles + ncu - 1) / ncu;
-  double cost = (double)rounds * (bn + 40.0);
+#ifndef MIYOLO_DMAP_C0
+#define MIYOLO_DMAP_C0 100.0
+#endif
+  double cost = (double)rounds * (bn + MIYOLO_DMAP_C0);
   if (c.wc == 1) cost *= 1.05;
   return cost;
 }

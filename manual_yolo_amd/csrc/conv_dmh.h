@@ -300,7 +300,7 @@ inline bool dmh_preferred_shape(int cout, long M, int ncu) {
   const long mbk = (M + DMA_BM - 1) / DMA_BM, nb = (cout + bn - 1) / bn, tiles = mbk * nb;
   if (tiles <= ncu || tiles > 2L * ncu) return false;
   // two workgroups share a CU: each tile takes ~1.7x as long (same-box timings), but all tiles run in one round
-  const double dmh_cost = 1.7 * (bn + 40.0) * (cd.wc == 1 ? 1.05 : 1.0);
+  const double dmh_cost = 1.7 * (bn + MIYOLO_DMAP_C0) * (cd.wc == 1 ? 1.05 : 1.0);
   return dmh_cost < dmap_cost(cout, M, ncu, pick_dmap_cfg(cout, M, ncu));
 }
 inline bool dmh_preferred(const ConvArgs& a, int ncu) { return dmh_preferred_shape(a.cout, a.M, ncu); }

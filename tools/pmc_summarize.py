@@ -29,7 +29,7 @@ def main():
     counts = defaultdict(int)
     dur = defaultdict(float)
     for g in sorted(os.listdir(root)):
-        files = glob.glob(os.path.join(root, g, "*", "*counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(root, g, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]   # newest run only
         for f in files:
             seen = set()
             for row in csv.DictReader(open(f)):
@@ -39,7 +39,7 @@ def main():
                 if g == "sq1" and key not in seen:
                     seen.add(key)
                     counts[k] += 1
-        for f in glob.glob(os.path.join(root, g, "*", "*kernel_trace.csv")):
+        for f in sorted(glob.glob(os.path.join(root, g, "*", "*kernel_trace.csv")), key=os.path.getmtime)[-1:]:
             if g != "sq1":
                 continue
             for row in csv.DictReader(open(f)):

@@ -16,7 +16,7 @@ from pmc_summarize import short  # noqa: E402
 root, out = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: {"fetch": 0.0, "write": 0.0, "n_fetch": 0, "n_write": 0})
 for g, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    for f in glob.glob(os.path.join(root, g, "*", "*counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(root, g, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:   # newest run only
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != cname:
                 continue
