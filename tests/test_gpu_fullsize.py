@@ -51,7 +51,8 @@ def _check_post_invariants(dets, counts, H, W, iou=0.7, max_det=300):
             assert (m * same).max() <= iou + 1e-2, "two kept boxes of one class overlap above the threshold"
 
 
-@pytest.mark.parametrize("dtype,B,H,W", [("f16", 64, 640, 640), ("f32", 32, 640, 640), ("f16", 16, 1280, 1280)])
+@pytest.mark.parametrize("dtype,B,H,W", [("f16", 64, 640, 640), ("f32", 32, 640, 640), ("f16", 16, 1280, 1280),
+                                         ("f16", 64, 544, 640), ("f32", 8, 1056, 1280)])   # the reference's 930x1130 frames letterboxed for imgsz 640 / 1280
 def test_fullsize_determinism_independence_and_nms_invariants(model, dtype, B, H, W):
     eng = model[dtype]
     frames = torch.from_numpy(synth_frames(B, H, W, seed=4, kind="noise")).cuda()
