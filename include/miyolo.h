@@ -161,10 +161,18 @@ int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, flo
 int miyolo_chunk(miyolo_handle h, int B, int H, int W);
 
 /* Options: "max_chunk" (images per pass, 0 = automatic), "force_wc"/"force_tc" (pin the conv
- * tile shape: waves along channels 1|2, 16-channel tiles per wave 1..4; tests and tuning),
+ * tile shape: waves along channels 1|2, 16-channel tiles per wave 1..6; tests and tuning),
  * "profile" (see miyolo_profile_read), "conv_impl" (0: register-staged double-buffered conv
  * kernel; 1: LDS-DMA 3-stage ring kernel; 2: as 1, plus the LDS halo-tile kernel for 3x3
- * stride-1 convolutions; 3 (default): persistent LDS-DMA ring kernel). */
+ * stride-1 convolutions; 3 (default): persistent LDS-DMA ring kernel, with the 2-D-tile kernel for
+ * narrow 3x3 layers; 4: persistent halo kernel; 5: warp-specialised kernel; 6: two workgroups
+ * per CU; 7: 2-D-tile kernel where eligible, else 3), "t2d" (1 default: conv_impl 3 uses the
+ * 2-D-tile kernel), "dmh_auto" (0 default: conv_impl 3 hands launches with 1-2 tiles per CU to
+ * kernel 6), "ncu" (width of the persistent grids, default = the device's CU count), "graph"
+ * (1: detect/classify calls are captured into a hipGraph and replayed while shape, thresholds,
+ * stream and pointers stay the same; needs a non-default stream; default 0), and the
+ * timing-experiment switches "ablate" / "dbg_op" of the non-shipped builds.  Setting any option
+ * drops the captured graphs. */
 int miyolo_set_option(miyolo_handle h, const char* key, int value);
 
 /* Debug/parity taps (B must not exceed miyolo_chunk): copy activation buffer `buf` out as /
