@@ -104,7 +104,17 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     const int q = e;                       // chunk index on the flattened K axis
     uint32_t v;
     if constexpr (KS == 3) {
+#ifdef MIYOLO_KORDER_EXPT     // timing experiment (results wrong: weights stay tap-major): channel-group-major K order, see DESIGN.md
+      int tp, co;
+      {
+        const int gfull = ct0 / 8, rem = ct0 - gfull * 8;
+        if (q < gfull * 72) { const int grp = q / 72, r = q - grp * 72; tp = r / 8; co = grp * 8 + (r - tp * 8); }
+        else if (rem > 0) { const int q2 = q - gfull * 72; tp = q2 / rem; co = gfull * 8 + (q2 - tp * rem); }
+        else { tp = 9; co = 0; }
+      }
+#else
       const int tp = q / ct0, co = q - tp * ct0;
+#endif
       v = (tp < 9) ? ((uint32_t)tp << 28) | (uint32_t)((((tp / 3) * a.src[0].w + tp % 3) * a.src[0].ld + co * CE) * (int)sizeof(T))
                    : (9u << 28);
     } else {
