@@ -29,6 +29,12 @@
 #ifndef MIYOLO_DMAP_BALANCED_GRID
 #define MIYOLO_DMAP_BALANCED_GRID 1
 #endif
+// Timing experiment (-DMIYOLO_HALO_EXPT=1, results wrong): the activation DMAs of the six taps with dx != 0 are sent out
+// of range (they still issue and write zeros, but move no data from L2) - an upper bound on what fetching each activation
+// once per row of taps instead of once per tap would buy, before any cost of doing so.
+#ifndef MIYOLO_HALO_EXPT
+#define MIYOLO_HALO_EXPT 0
+#endif
 #ifndef MIYOLO_DMAP_EXACT_VMCNT
 #define MIYOLO_DMAP_EXACT_VMCNT 1
 #endif
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       const uint32_t tp = e >> 28, kofs = e & 0x0FFFFFFFu;
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
-        const uint32_t off = (((uint32_t)xoff0[i] + kofs) | (((xinv[i] >> tp) & 1u) << 31)) & ab_and;
+        const uint32_t off = ((((uint32_t)xoff0[i] + kofs) | (((xinv[i] >> tp) & 1u) << 31)) & ab_and) | ((MIYOLO_HALO_EXPT && (tp % 3) != 1) ? 0x80000000u : 0u);
         lds_dma16(rs0, st + i * 8192, off);
       }
     } else {
@@ -270,12 +276,13 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     const int ks = d_ks;
     const uint32_t e = ktab[ks * 8 + cg];
     const uint32_t tp = e >> 28;
+    const uint32_t k3_expt = (MIYOLO_HALO_EXPT && KS == 3 && (tp % 3) != 1) ? 0x80000000u : 0u;   // timing experiment, see below
     const uint32_t kofs = (KS == 3) ? (e & 0x0FFFFFFFu) : (e & 0x8FFFFFFFu);
     const bool seg1 = (KS == 1) && (ks * 8) >= ct0;
     auto issue_one = [&](int d) {
       if (d < XI) {
         if constexpr (KS == 3) {
-          lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | (((xinv[d] >> tp) & 1u) << 31));
+          lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | (((xinv[d] >> tp) & 1u) << 31) | k3_expt);
         } else {
           if (!seg1) lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | xinv[d]);
           else lds_dma16(rs1, st + d * 8192, ((uint32_t)xoff1[KS == 1 ? d : 0] + kofs) | xinv[d]);
