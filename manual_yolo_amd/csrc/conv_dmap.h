@@ -35,6 +35,11 @@
 #ifndef MIYOLO_HALO_EXPT
 #define MIYOLO_HALO_EXPT 0
 #endif
+// L2 warm-up: when the DMA stream moves on to a tile, touch the activation lines of
+// the tile AFTER it with plain loads, so that the ring's DMAs find them in L2 a tile later.
+#ifndef MIYOLO_DMAP_L2WARM
+#define MIYOLO_DMAP_L2WARM 0
+#endif
 #ifndef MIYOLO_DMAP_EXACT_VMCNT
 #define MIYOLO_DMAP_EXACT_VMCNT 1
 #endif
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   uint32_t xinv[XI];         // 3x3: bit t = tap t OUTSIDE the image (bit 9 always set); 1x1: 0 / 0x80000000
   uint32_t woff[NI - XI];
   int d_tile = first, d_ks = 0, d_slot = 0, d_issued = 0;
+  int v_stores = 0;                      // vector memory ops issued since the last DMA of the youngest stage (wave-uniform)
 
   // Per-lane row state of `tile`.  DMA i of this wave covers rows 8*(wave + 8*i) + (lane >> 3) and the 8 lanes of a
   // row group share a row, so computing per (lane, i) would do every row 8 times over.  Lane L computes ONE row -
@@ -187,6 +193,35 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     }
   };
 
+  // L2 warm-up of `tile` (3x3 stride-1, single source): lanes 0-31 of a wave own 32 of the tile's 256 pixels (as in
+  // setup_tile); lanes 32-63 take the same pixels' second 128-byte line.  Plain dword loads through the raw buffer
+  // (out of range -> nothing fetched); their results are summed into `warm_acc`, which is only "used" at the very end,
+  // so the compiler never waits for them inside the loop.  They are counted in v_stores for the ring's vmcnt.
+  float warm_acc = 0.f;
+  const __amdgpu_buffer_rsrc_t rwarm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src[0].ptr), 0, a.src[0].bytes, 0x00020000);
+  auto warm_tile = [&](int tile) -> int {
+    if constexpr (!(MIYOLO_DMAP_L2WARM && KS == 3)) { return 0; }
+    else {
+      if (a.stride != 1) return 0;
+      const int mb = tile / NB;
+      const int m = mb * BM + 8 * (wave + 8 * ((lane >> 3) & (XI - 1))) + (lane & 7);
+      const bool vm = m < a.M;
+      const int cinB = a.cin * (int)sizeof(T);
+      const int line = (lane >> 5) * 128;
+      const uint32_t base = (uint32_t)((m * a.src[0].ld + a.src[0].ch_off) * (int)sizeof(T));      // stride 1: input pixel = output pixel
+      int n = 0;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {                          // lines 0/128 then 256/384 of the pixel's channel slice
+        if (l * 256 < cinB) {                                // wave-uniform
+          const uint32_t off = (vm && line + l * 256 < cinB) ? base + (uint32_t)(line + l * 256) : 0x80000000u;
+          warm_acc += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwarm, off, 0, 0));
+          ++n;
+        }
+      }
+      return n;
+    }
+  };
+
   // issue the NI DMAs of the DMA stream's next (tile, K step); branch-free validity (conv_dma.h)
   // timing experiments (a.ablate, results wrong): 1 = no tile DMA, 128 = activation offsets wrapped
   // into a 1 MiB window (everything L2 resident), 256 = activation rows forced to 128-byte alignment
@@ -231,7 +266,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     if (++d_ks == a.nk) {                 // DMA stream moves on to this workgroup's next tile
       d_ks = 0;
       d_tile += G;
-      if (d_tile < ntiles) setup_tile(d_tile);
+      if (d_tile < ntiles) { setup_tile(d_tile); if (d_tile + G < ntiles) v_stores += warm_tile(d_tile + G); }
     }
   };
 
@@ -320,7 +355,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       if (++d_ks == a.nk) {
         d_ks = 0;
         d_tile += G;
-        if (d_tile < ntiles) setup_tile(d_tile);
+        if (d_tile < ntiles) { setup_tile(d_tile); if (d_tile + G < ntiles) v_stores += warm_tile(d_tile + G); }
       }
     }
   };
@@ -379,7 +414,6 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   if (NST > 2 && total_steps > 1) issue_next();
 
   int c_tile = first, c_ks = 0, c_slot = 0;
-  int v_stores = 0;                      // vector stores issued since the last DMA of the youngest stage (wave-uniform)
 #if MIYOLO_ABLATE
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, acc_epi = 0, t_begin = 0;
   STAMP(t_begin);
@@ -393,7 +427,8 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #define MIYOLO_WAIT(K) case (K): asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NI + (K)) : "memory"); break;
       switch (MIYOLO_DMAP_EXACT_VMCNT ? v_stores : 0) {
         MIYOLO_WAIT(0) MIYOLO_WAIT(1) MIYOLO_WAIT(2) MIYOLO_WAIT(3) MIYOLO_WAIT(4) MIYOLO_WAIT(5) MIYOLO_WAIT(6) MIYOLO_WAIT(7) MIYOLO_WAIT(8)
-        MIYOLO_WAIT(12) MIYOLO_WAIT(16)
+        MIYOLO_WAIT(9) MIYOLO_WAIT(10) MIYOLO_WAIT(11) MIYOLO_WAIT(12) MIYOLO_WAIT(13) MIYOLO_WAIT(14) MIYOLO_WAIT(15) MIYOLO_WAIT(16)
+        MIYOLO_WAIT(17) MIYOLO_WAIT(18) MIYOLO_WAIT(19) MIYOLO_WAIT(20)
         default: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NI) : "memory"); break;   // uncounted: conservative
       }
 #undef MIYOLO_WAIT
@@ -502,6 +537,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   if constexpr (DEFER_CT) {
     for (; e_next < NP; ++e_next) run_piece(e_next);           // the last tile's pieces
   }
+  if (MIYOLO_DMAP_L2WARM && warm_acc == 1.2345e-30f && a.dbg) a.dbg[0] = 1;   // never true: keeps the warm-up loads alive
 #if MIYOLO_ABLATE
   if (a.dbg && lane == 0) {          // per wave: total, wait, issue, compute, epilogue cycles + steps
     STAMP(t4);
