@@ -3,7 +3,7 @@
 // Why: profiles/r01_per_layer_f16.md - the 48->48 3x3 layers at 160x160 are HBM-bound by the layer-wise roofline
 // (216 FLOP per compulsory byte) but ran at 0.18 of it: the ring kernels re-fetch the activation tile once per tap and
 // the weight tile once per pixel tile, 1.06 KB of L2 -> LDS traffic per output pixel against 192 B of HBM traffic, and
-// that path (not the matrix pipe) is what bounds them.  Here a persistent workgroup
+// the fill (its DMA instructions), not the matrix pipe, is what bounds them.  Here a persistent workgroup
 //   * loads the layer's WHOLE weight matrix into LDS once (48 x 432 halves = 42 KiB),
 //   * per 16 x 16 pixel tile fetches the 18 x 18 halo tile ONCE (all channels, zero-filled outside the image by the
 //     LDS-DMA's out-of-range rule), double-buffered against the MFMAs of the previous tile,
