@@ -40,6 +40,12 @@
 #ifndef MIYOLO_DMAP_L2WARM
 #define MIYOLO_DMAP_L2WARM 0
 #endif
+// The interleaved step issues its DMAs unconditionally - in the last two steps of a workgroup, where there is nothing left
+// to fetch, with every offset out of range (zeros into a slot nobody reads) - so that no scalar branch sits between the
+// MFMAs (tools/probes/probe_step.hip: interleaving is worth 22 % in the bare skeleton).  Measured: -0.2 % on the step, so off.
+#ifndef MIYOLO_DMAP_ALWAYS_ISSUE
+#define MIYOLO_DMAP_ALWAYS_ISSUE 0
+#endif
 #ifndef MIYOLO_DMAP_EXACT_VMCNT
 #define MIYOLO_DMAP_EXACT_VMCNT 1
 #endif
@@ -314,16 +320,17 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     const uint32_t k3_expt = (MIYOLO_HALO_EXPT && KS == 3 && (tp % 3) != 1) ? 0x80000000u : 0u;   // timing experiment, see below
     const uint32_t kofs = (KS == 3) ? (e & 0x0FFFFFFFu) : (e & 0x8FFFFFFFu);
     const bool seg1 = (KS == 1) && (ks * 8) >= ct0;
+    const uint32_t dead = (MIYOLO_DMAP_ALWAYS_ISSUE && !do_issue) ? 0x80000000u : 0u;
     auto issue_one = [&](int d) {
       if (d < XI) {
         if constexpr (KS == 3) {
-          lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | (((xinv[d] >> tp) & 1u) << 31) | k3_expt);
+          lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | (((xinv[d] >> tp) & 1u) << 31) | k3_expt | dead);
         } else {
-          if (!seg1) lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | xinv[d]);
-          else lds_dma16(rs1, st + d * 8192, ((uint32_t)xoff1[KS == 1 ? d : 0] + kofs) | xinv[d]);
+          if (!seg1) lds_dma16(rs0, st + d * 8192, ((uint32_t)xoff0[d] + kofs) | xinv[d] | dead);
+          else lds_dma16(rs1, st + d * 8192, ((uint32_t)xoff1[KS == 1 ? d : 0] + kofs) | xinv[d] | dead);
         }
       } else {
-        lds_dma16(rsw, st + BM * ROW_BYTES + (d - XI) * 8192, woff[d - XI] + (uint32_t)(ks * 128));
+        lds_dma16(rsw, st + BM * ROW_BYTES + (d - XI) * 8192, (woff[d - XI] + (uint32_t)(ks * 128)) | dead);
       }
     };
     constexpr int NM = 2 * TC * TPW;                 // MFMAs of the step
@@ -346,9 +353,10 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
           const int q = (kk * TC + i) * TPW + j;     // constant after unrolling
 #pragma unroll
           for (int d = 0; d < NI; ++d)
-            if (q == (d * NM) / NI) { if (do_issue) issue_one(d); }
+            if (q == (d * NM) / NI) { if (MIYOLO_DMAP_ALWAYS_ISSUE || do_issue) issue_one(d); }
         }
     }
+    if (MIYOLO_DMAP_ALWAYS_ISSUE && !do_issue) d_slot = (d_slot == NST - 1) ? 0 : d_slot + 1;
     if (do_issue) {
       d_slot = (d_slot == NST - 1) ? 0 : d_slot + 1;
       ++d_issued;
@@ -537,6 +545,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   if constexpr (DEFER_CT) {
     for (; e_next < NP; ++e_next) run_piece(e_next);           // the last tile's pieces
   }
+  if (MIYOLO_DMAP_ALWAYS_ISSUE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead DMAs of the last steps
   if (MIYOLO_DMAP_L2WARM && warm_acc == 1.2345e-30f && a.dbg) a.dbg[0] = 1;   // never true: keeps the warm-up loads alive
 #if MIYOLO_ABLATE
   if (a.dbg && lane == 0) {          // per wave: total, wait, issue, compute, epilogue cycles + steps
