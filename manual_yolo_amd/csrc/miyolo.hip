@@ -16,12 +16,21 @@
 #include "common.h"
 #include "conv_igemm.h"
 #include "conv_dma.h"
-#include "conv_halo.h"
 #include "conv_dmap.h"
+#include "conv_t2d.h"
+#include "conv_h2.h"
+// Earlier kernel generations / experiments (persistent halo, warp-specialised, two-workgroup, first halo prototype):
+// compiled only with `build.sh experiments` (-DMIYOLO_EXPERIMENTS=1); the shipped library carries conv_igemm.h
+// (conv_impl 0) and conv_dma.h (1) as the simple bit-exact cross-checks of the default kernels.
+#ifndef MIYOLO_EXPERIMENTS
+#define MIYOLO_EXPERIMENTS 0
+#endif
+#if MIYOLO_EXPERIMENTS
+#include "conv_halo.h"
 #include "conv_halop.h"
 #include "conv_ws.h"
 #include "conv_dmh.h"
-#include "conv_t2d.h"
+#endif
 #include "kernels_misc.h"
 #include "nms.h"
 #include "preprocess.h"
@@ -58,6 +67,8 @@ struct miyolo_engine {
   std::vector<GraphRec> graphs;
   int dmh_auto = 0;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h); off since the
                             // balanced grids: +0.2 % without it (same-box A/B), it won only by removing a half-empty round
+  int h2 = 1;               // conv_impl 3: 3x3 stride-1 layers on the halo-slab kernel (conv_h2.h) where its tiles cover the map well
+  int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
@@ -150,6 +161,7 @@ hipError_t set_t2d_attrs() {
   return hipSuccess;
 }
 
+#if MIYOLO_EXPERIMENTS
 template <typename T, int KS>
 hipError_t set_dmh_attrs_ks() {
   hipError_t e;
@@ -197,6 +209,7 @@ hipError_t set_halo_attrs() {
 #undef MIYOLO_HALO_ATTR
   return hipSuccess;
 }
+#endif  // MIYOLO_EXPERIMENTS
 
 int nms_lds_bytes(int max_det) { return ((max_det * 5 * 4 + 15) & ~15) + kNmsLdsKeys * 8; }
 
@@ -346,14 +359,18 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
-      if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && t2d_eligible<T>(a))
+      if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s));
+      else if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && t2d_eligible<T>(a))
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
+      else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) HIP_TRY(h, launch_conv_h2<T>(a, s));
+#if MIYOLO_EXPERIMENTS
       else if ((h->conv_impl == 6 || (h->conv_impl == 3 && h->dmh_auto && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
         HIP_TRY(h, launch_conv_dmh<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 5) HIP_TRY(h, launch_conv_ws<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 4 && halop_eligible(a)) HIP_TRY(h, launch_conv_halop<T>(a, s, h->ncu, h->force_wc, h->force_tc));
-      else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
+#endif
+      else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
       else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
       break;
@@ -414,23 +431,37 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   if (op.kind != MIYOLO_OP_CONV) return 0;
   const miyolo_buf& ob = h->bufs[op.dst.buf];
   const long M = (long)p.B * (p.H / ob.down) * (p.W / ob.down);
-  const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
-                    halo_xi(p.W / ob.down) <= 8;
-  const bool halop = h->conv_impl == 4 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
-                     (p.W / ob.down) <= 95 && op.cout % 4 == 0;
-  const int bk = 8 * (h->desc.dtype == MIYOLO_F16 ? 8 : 4);
-  const size_t dmh_lds = dmh_lds_bytes() + (size_t)((op.cin * op.ksize * op.ksize + bk - 1) / bk) * 32;
-  const bool dmh_auto = h->conv_impl == 3 && h->dmh_auto && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
   T2dGeom tg; size_t tlds;
   const bool t2d = (h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && op.ksize == 3 && op.stride == 1 &&
                    op.n_src == 1 && !op.src[0].upsample &&
                    t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
+  const bool s1 = op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample && ob.dtype != MIYOLO_F32 && op.cout % 8 == 0;
+  if (s1 && (h->conv_impl == 8 || (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && !t2d))) {
+    H2Geom hg; size_t hl;
+    const int es = h->desc.dtype == MIYOLO_F16 ? 2 : 4, tc = h2_pick_tc(op.cout);
+    if (h2_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, es, 16 / es, tc, &hg, &hl) &&
+        (h->conv_impl == 8 || h2_util(hg, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h2_min_util))
+      return 8000 + 300 + 40 + tc;                          // conv_h2_kernel<T,TC>
+  }
   if (t2d) return 7000 + 300 + 10 + (op.cout + 15) / 16;   // conv_t2d_kernel<T,TC>
-  const int impl = (h->conv_impl == 6 || dmh_auto) ? 6 : h->conv_impl == 5 ? 5 : halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
-  ConvCfg c = impl == 6 ? pick_dma_cfg(op.cout, M) : impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
-              : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
+  int impl = h->conv_impl >= 3 ? 3 : (h->conv_impl >= 1 ? 1 : 0);
+  ConvCfg c = impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
+#if MIYOLO_EXPERIMENTS
+  {
+    const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
+                      halo_xi(p.W / ob.down) <= 8;
+    const bool halop = h->conv_impl == 4 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
+                       (p.W / ob.down) <= 95 && op.cout % 4 == 0;
+    const int bk = 8 * (h->desc.dtype == MIYOLO_F16 ? 8 : 4);
+    const size_t dmh_lds = dmh_lds_bytes() + (size_t)((op.cin * op.ksize * op.ksize + bk - 1) / bk) * 32;
+    const bool dmh_auto = h->conv_impl == 3 && h->dmh_auto && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
+    impl = (h->conv_impl == 6 || dmh_auto) ? 6 : h->conv_impl == 5 ? 5 : halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
+    c = impl == 6 ? pick_dma_cfg(op.cout, M) : impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
+        : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
+  }
+#endif
   if (h->force_wc > 0 && h->force_tc > 0) c = {h->force_wc, h->force_tc};
-  return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 2323 = conv_halo_kernel<T,2,3>
+  return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 3323 = conv_dmap_kernel<T,3,2,3>
 }
 
 int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
@@ -567,8 +598,11 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_dmap_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 3>();
+  if (e == hipSuccess) e = set_h2_attrs<float>();
+  if (e == hipSuccess) e = set_h2_attrs<half_t>();
   if (e == hipSuccess) e = set_t2d_attrs<float>();
   if (e == hipSuccess) e = set_t2d_attrs<half_t>();
+#if MIYOLO_EXPERIMENTS
   if (e == hipSuccess) e = set_dmh_attrs_ks<float, 1>();
   if (e == hipSuccess) e = set_dmh_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_dmh_attrs_ks<half_t, 1>();
@@ -581,6 +615,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_halop_attrs<half_t>();
   if (e == hipSuccess) e = set_halo_attrs<float>();
   if (e == hipSuccess) e = set_halo_attrs<half_t>();
+#endif
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_greedy_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, nms_lds_bytes(1024));
@@ -604,8 +639,14 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "force_wc")) { h->force_wc = value; return 0; }
   if (!strcmp(key, "force_tc")) { h->force_tc = value; return 0; }
   if (!strcmp(key, "profile")) { h->profile = value; return 0; }
-  if (!strcmp(key, "conv_impl")) { h->conv_impl = value; return 0; }
+  if (!strcmp(key, "conv_impl")) {
+    if (!MIYOLO_EXPERIMENTS && (value == 2 || value == 4 || value == 5 || value == 6))
+      return fail(h, MIYOLO_ERR_UNSUPPORTED, "conv_impl %d is an experimental kernel: rebuild with csrc/build.sh experiments", value);
+    h->conv_impl = value; return 0;
+  }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
+  if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
+  if (!strcmp(key, "h2_min_util")) { h->h2_min_util = value; return 0; }
   if (!strcmp(key, "dmh_auto")) { h->dmh_auto = value; return 0; }
   if (!strcmp(key, "ncu")) { if (value < 8 || value > 1024) return fail(h, MIYOLO_ERR_ARG, "ncu out of range"); h->ncu = value; return 0; }   // persistent-grid width (A/B)
   if (!strcmp(key, "ablate")) { h->ablate = value; return 0; }

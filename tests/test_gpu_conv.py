@@ -21,7 +21,7 @@ def ref_conv(x, w, b, s, act, res=None):
     return y + res if res is not None else y
 
 
-IMPLS = [0, 1, 2, 3, 4, 5, 6, 7]   # 7: narrow 3x3 layers on 16x16 tiles with LDS-resident weights (conv_t2d.h; other shapes fall through to the ring kernel); 6: half-size stages, two workgroups per CU (conv_dmh.h); 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
+IMPLS = [0, 1, 3, 7, 8]   # 8: halo-slab kernel for 3x3 stride-1 layers (conv_h2.h; other shapes fall through to the ring kernel); impls 2, 4, 5, 6 (conv_halo/halop/ws/dmh) are experiments, compiled only by `csrc/build.sh experiments` and then tested by MIYOLO_TEST_EXPERIMENTS=1; 7: narrow 3x3 layers on 16x16 tiles with LDS-resident weights (conv_t2d.h; other shapes fall through to the ring kernel); 6: half-size stages, two workgroups per CU (conv_dmh.h); 5: warp-specialised producer/consumer ring (conv_ws.h); 3: persistent LDS-DMA ring (conv_dmap.h); 4: 3 + persistent halo kernel (conv_halop.h); 0: register-staged (conv_igemm.h); 1: LDS-DMA ring (conv_dma.h); 2: 1 + halo kernel for 3x3 s1 (conv_halo.h)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -130,7 +130,7 @@ def test_head_final_conv_f32_out(dtype, cout, impl):
     (288, 288, 20, 20, 4, None),      # 4.5 chunks: trailing 32-channel chunk
     (80, 64, 24, 94, 1, (1, 4)),      # widest map the persistent halo kernel takes, 1.25 chunks
 ])
-@pytest.mark.parametrize("impl", [2, 4])
+@pytest.mark.parametrize("impl", [2, 4, 8])
 def test_halo_kernel_shapes(dtype, cin, cout, H, W, B, force, impl):
     """conv_halo.h / conv_halop.h: shifted LDS windows, zero-row masking at frame borders, halo pieces
     (shapes the persistent variant does not take - width > 95 - fall back to the ring kernel)."""
@@ -181,12 +181,13 @@ def test_one_to_two_tiles_per_cu(dtype, cin, cout, k, H, W, B):
     w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
     res = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype)
-    y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=3)
-    y6 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=6)
+    y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=3, opts={"h2": 0})
     y1 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=1)
     assert rel_err(y3, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
     if dtype == "f32":
-        assert np.array_equal(y3, y1) and np.array_equal(y6, y1)   # same accumulation order in all kernels: bit-identical in the exact mode
+        assert np.array_equal(y3, y1)   # same accumulation order in the ring kernels: bit-identical in the exact mode
+    yd = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, 1, True, res, B, H, W, impl=3)      # default engine (halo-slab kernel for the 3x3)
+    assert rel_err(yd, ref_conv(x, w, b, 1, True, res)) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
@@ -220,6 +221,48 @@ def test_t2d_channel_slices(dtype):
     w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
     b = rng.standard_normal(cout).astype(np.float32)
     y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96, impl=7)
+    ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
+    assert rel_err(y[..., 96:96 + cout], ref) < TOL[dtype]
+    assert np.all(y[..., :96] == 7.0) and np.all(y[..., 96 + cout:] == 7.0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cin,cout,H,W,B,res", [
+    (96, 96, 80, 80, 2, True),        # 16x16 tiles, pitch 24 (odd dy flips the row halves), 1.5 chunks
+    (192, 192, 40, 40, 2, False),     # 40x6 tiles (pitch 48), 240 of 256 pixels used, two channel tiles
+    (288, 288, 20, 20, 3, True),      # 20x12 tiles, 4.5 chunks, three channel tiles
+    (48, 48, 160, 160, 1, True),      # TC = 3: one pair + an unpaired channel tile
+    (192, 64, 80, 80, 1, False),      # head box branch, TC = 4
+    (384, 192, 40, 40, 1, False),
+    (576, 64, 20, 20, 2, False),
+    (64, 64, 20, 20, 2, False),       # one chunk exactly
+    (96, 72, 68, 80, 1, True),        # letterboxed 544x640 frame: 68-wide map; channel tail (72 of 96)
+    (96, 96, 17, 20, 2, False),       # odd height
+    (16, 16, 16, 16, 3, True),        # classifier sizes: a quarter chunk
+    (32, 200, 12, 20, 2, False),      # cout 200 = 2 x 96 + 8
+    (24, 40, 9, 7, 5, True),          # tiny maps, several tiles idle rows/columns
+])
+def test_h2_kernel_shapes(dtype, cin, cout, H, W, B, res):
+    """conv_h2.h (conv_impl 8, and the default engine where its tiles cover the map): slab pitch classes, partial tiles
+    on every side, channel chunk tails, paired / unpaired channel tiles, residual."""
+    rng = np.random.default_rng(cin * 7 + cout + H)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype) if res else None
+    y = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=8)
+    assert rel_err(y, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_h2_channel_slices(dtype):
+    """input = channels 48..95 of a 96-channel buffer, output into channels 96..143 of a 192-channel buffer."""
+    rng = np.random.default_rng(78)
+    B, H, W, ld, off, cin, cout = 2, 40, 40, 96, 48, 48, 48
+    x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96, impl=8)
     ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
     assert rel_err(y[..., 96:96 + cout], ref) < TOL[dtype]
     assert np.all(y[..., :96] == 7.0) and np.all(y[..., 96 + cout:] == 7.0)
