@@ -172,7 +172,7 @@ def main():
                                        "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl0, "bytes": by0})
             e0["n"] += 1; e0["ms"] += ms
         for op, cfg, ms in recs:
-            k = ("%s<%s,k%d,wc%d,tc%d>" % ("conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else "conv_halop" if cfg >= 4000 else "conv_dmap" if cfg >= 3000 else "conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm", args.dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)) if cfg else \
+            k = ("%s<%s,k%d,wc%d,tc%d>" % ("conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else "conv_halop" if cfg >= 4000 else "conv_dmap" if cfg >= 3000 else "conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm", args.dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)) if cfg else \
                 {0: "stem", 2: "maxpool5", 3: "decode", 4: "cls_head"}.get(eng.prog.ops[op].kind, "op")
             fl, by = eng.op_work(op, min(chunk, B), H, W)
             e = per.setdefault(k, [0, 0.0, 0.0, 0.0])

@@ -5,7 +5,7 @@ The reference loads weights with ``YOLO("rank_classifier.pt")`` / ``YOLO("poker_
 ``{'model': nn.Module, 'train_args': ..., ...}`` whose classes live in ``ultralytics.*``
 and ``torchvision.*``.  Neither package is needed to read the numbers: a restricted
 unpickler maps those classes to inert stand-ins and only lets ``torch``/``collections``/
-builtins through, so the file yields its state dict, ``names``, ``yaml`` spec and task.
+an explicit allowlist of builtins through, so the file yields its state dict, ``names``, ``yaml`` spec and task.
 
 ``save_bundle``/``load_bundle`` keep the same information as one ``.safetensors`` file
 (raw tensors, original dtypes) with the metadata JSON in its header - that is the format
@@ -20,8 +20,30 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
-_ALLOWED_EXACT = {"collections", "__builtin__", "builtins", "_codecs",
-                  "numpy", "numpy.core.multiarray", "numpy._core.multiarray"}
+# Explicit (module, name) allowlist: exactly the globals an Ultralytics 8.x checkpoint references (probe of
+# rank_classifier.pt's pickle stream) plus what torch's own tensor rebuilding needs.  Anything else - builtins.eval,
+# torch.utils.collect_env.run, torch.hub.load, os.system, ... - raises: a crafted .pt cannot execute code through this
+# loader (tests/test_ckpt_safety.py).
+_ALLOWED = {
+    ("collections", "OrderedDict"),
+    ("builtins", "set"), ("builtins", "slice"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+    ("builtins", "complex"), ("builtins", "frozenset"), ("builtins", "range"), ("builtins", "bytearray"),
+    ("__builtin__", "set"), ("__builtin__", "slice"), ("__builtin__", "dict"), ("__builtin__", "list"),
+    ("__builtin__", "tuple"), ("__builtin__", "int"), ("__builtin__", "float"), ("__builtin__", "bool"),
+    ("__builtin__", "str"), ("__builtin__", "frozenset"), ("__builtin__", "range"),
+    ("_codecs", "encode"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"),
+    ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
+}
+_ALLOWED_STORAGES = {"DoubleStorage", "FloatStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+                     "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage"}
+_ALLOWED_DTYPES = {"float16", "float32", "float64", "bfloat16", "int8", "int16", "int32", "int64", "uint8", "bool"}
 
 
 class _Inert:
@@ -37,13 +59,31 @@ class _Inert:
             self.__dict__["_state"] = state
 
 
+def _allowed_global(module: str, name: str):
+    if (module, name) in _ALLOWED:
+        return True
+    if module == "torch" and (name in _ALLOWED_STORAGES or name in _ALLOWED_DTYPES):
+        return True
+    if module == "torch.storage" and name in ("_load_from_bytes", "UntypedStorage", "TypedStorage"):
+        return name != "_load_from_bytes"      # _load_from_bytes unpickles again with the default unpickler: refused
+    # plain torch.nn layer classes (Conv2d, BatchNorm2d, SiLU, Sequential, ...): classes defined under torch.nn.modules only
+    if module.startswith("torch.nn.modules.") and name[:1].isupper():
+        import importlib
+        try:
+            obj = getattr(importlib.import_module(module), name)
+        except Exception:
+            return False
+        return isinstance(obj, type) and issubclass(obj, nn.Module)
+    return False
+
+
 class _RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module.startswith("ultralytics."):
             return type(name, (nn.Module,), {"__module__": module})
         if module.startswith("torchvision."):
             return type(name, (_Inert,), {"__module__": module})
-        if module == "torch" or module.startswith("torch.") or module in _ALLOWED_EXACT:
+        if _allowed_global(module, name):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"blocked global {module}.{name}")
 

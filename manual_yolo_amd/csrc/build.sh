@@ -10,5 +10,5 @@ if [ "${1:-}" = "ablate" ]; then EXTRA=(-DMIYOLO_ABLATE=1); shift; fi   # timing
 if [ "${1:-}" = "experiments" ]; then EXTRA=(-DMIYOLO_EXPERIMENTS=1); shift; fi   # + conv_halo/halop/ws/dmh (conv_impl 2,4,5,6)
 if [ "${1:-}" = "stamps" ]; then EXTRA=(-DMIYOLO_ABLATE=2); shift; fi   # in-kernel cycle stamps only, never shipped
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
-  -o libmiyolo.so miyolo.hip "${EXTRA[@]}" "$@"
-echo "built $(pwd)/libmiyolo.so"
+  -o "${OUT:-libmiyolo.so}" miyolo.hip "${EXTRA[@]}" "$@"
+echo "built $(pwd)/${OUT:-libmiyolo.so}"

@@ -41,6 +41,14 @@ __device__ __forceinline__ void lds_dma16(const v4i_t rsrc, uint32_t lds_addr, u
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
 }
+// The 4-byte form (lane l lands at lds_addr + 4*l): used to touch cache lines (L2 warm-up), the data is never read.
+__device__ __forceinline__ void lds_dma4(const v4i_t rsrc, uint32_t lds_addr, uint32_t voff) {
+  const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  const v4i_t rs = {__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]),
+                    __builtin_amdgcn_readfirstlane(rsrc[2]), __builtin_amdgcn_readfirstlane(rsrc[3])};
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+}
 __device__ __forceinline__ v4i_t make_srd(const void* p, uint32_t bytes) {
   const unsigned long long a = (unsigned long long)p;
   return (v4i_t){(int)(uint32_t)a, (int)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};

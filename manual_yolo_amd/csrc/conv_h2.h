@@ -32,18 +32,33 @@ struct H2Geom {
   int32_t TW, TH, HP, GX;            // tile width / height (pixels), slab pitch (LDS rows per halo row), 8-pixel DMA groups per halo row
   int32_t tiles_x, tiles_y, NB;      // pixel tiles per image row / column, channel tiles
   int32_t ntiles, nchunk, npx;       // workgroups, 128-byte channel chunks of cin, TH*TW (<= 256)
-  int32_t slab_bytes, flip;          // (TH+2)*HP*128; 1: HP % 16 == 8
+  int32_t slab_bytes, scratch_off;   // (TH+2)*HP*128; LDS offset of the 256-byte landing area of the warm-up DMAs
   uint32_t mg_tw_mul, mg_tw_shift;   // magic division by TW
   uint32_t mg_nb_mul, mg_nb_shift;   // by NB
   uint32_t mg_tx_mul, mg_tx_shift;   // by tiles_x
   uint32_t mg_ty_mul, mg_ty_shift;   // by tiles_y
   uint32_t bias_bytes;               // padded bias array size
+  int32_t warm;                      // unused (L2 warm-up experiments: no gain, removed)
 };
 
 constexpr int kH2LdsMax = 80 * 1024;     // two workgroups per CU
 
-template <typename T, int TC>
+// Tile geometries (compile-time: scalar setup code is slow on this machine - with run-time geometry the slab issue loop
+// cost ~300 cycles per DMA and the per-workgroup prologue >10 k cycles, gpurun stamps): TW x TH pixels, slab pitch HP.
+template <int GEO> struct H2Geo;
+template <> struct H2Geo<0> { static constexpr int TW = 16, TH = 16, HP = 24; };   // 160-, 80-wide maps (and anything else)
+template <> struct H2Geo<1> { static constexpr int TW = 40, TH = 6, HP = 48; };    // 40-wide maps
+template <> struct H2Geo<2> { static constexpr int TW = 20, TH = 12, HP = 24; };   // 20-wide maps
+inline void h2_geo(int geo, int* tw, int* th, int* hp) {
+  *tw = geo == 1 ? 40 : geo == 2 ? 20 : 16; *th = geo == 1 ? 6 : geo == 2 ? 12 : 16; *hp = geo == 1 ? 48 : 24;
+}
+
+template <typename T, int TC, int GEO>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const H2Geom g) {
+  constexpr int TW = H2Geo<GEO>::TW, TH = H2Geo<GEO>::TH, HP = H2Geo<GEO>::HP;
+  constexpr int GX = (TW + 2 + 7) / 8, NPX = TW * TH;
+  constexpr int SLAB = (TH + 2) * HP * ROW_BYTES;
+  constexpr int RPW = (TH + 2 + 3) / 4;          // halo rows per wave
   constexpr int ES = (int)sizeof(T);
   constexpr int CE = DT<T>::CE;
   constexpr int CPR = 8 * CE;                    // channels per 128-byte row
@@ -59,112 +74,131 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fq = lane >> 4;
+  const int H = a.Hin, W = a.Win;
 
-  // ---- workgroup -> tile: XCD-contiguous renumbering (bijective), channel tile fastest so that the channel tiles
-  // sharing a halo run side by side on one XCD
+  // ---- one tile per workgroup (the hardware's dynamic dispatch balanced better than static tile lists: persistent
+  // workgroups with the next tile's slab issued under the epilogue measured 3-10 % slower per layer); XCD-contiguous
+  // renumbering (bijective), channel tile fastest, so the channel tiles sharing a halo run side by side on one XCD
   int L = blockIdx.x;
   {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = L & 7, slot = L >> 3;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = L & 7, slot_ = L >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot_;
   }
-  uint32_t t1 = magic_div((uint32_t)L, g.mg_nb_mul, g.mg_nb_shift);
-  const int nb = L - (int)t1 * g.NB;
-  uint32_t t2 = magic_div(t1, g.mg_tx_mul, g.mg_tx_shift);
-  const int tx = (int)(t1 - t2 * (uint32_t)g.tiles_x);
-  const uint32_t bimg = magic_div(t2, g.mg_ty_mul, g.mg_ty_shift);
-  const int ty = (int)(t2 - bimg * (uint32_t)g.tiles_y);
-  const int y0 = ty * g.TH, x0 = tx * g.TW, n0 = nb * BN;
-  const int H = a.Hin, W = a.Win;
 
   const v4i_t rs0 = make_srd(a.src[0].ptr, a.src[0].bytes);
   const v4i_t rsw = make_srd(a.w, a.wbytes);
   const uint32_t lds_base = (uint32_t)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   const int ldB = a.src[0].ld * ES;
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.dst), 0, a.res ? a.res_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, g.bias_bytes, 0x00020000);
+
+  struct Tile { int bimg, y0, x0, n0; };
+  auto tile_coords = [&](int L) -> Tile {
+    const uint32_t t1 = magic_div((uint32_t)L, g.mg_nb_mul, g.mg_nb_shift);
+    const int nb = L - (int)t1 * g.NB;
+    const uint32_t t2 = magic_div(t1, g.mg_tx_mul, g.mg_tx_shift);
+    const int tx = (int)(t1 - t2 * (uint32_t)g.tiles_x);
+    const uint32_t bi = magic_div(t2, g.mg_ty_mul, g.mg_ty_shift);
+    const int ty = (int)(t2 - bi * (uint32_t)g.tiles_y);
+    return Tile{(int)bi, ty * TH, tx * TW, nb * BN};
+  };
 
   // ---- weight DMA rows of this lane: LDS row r of a slot holds channel n0 + pi(r), pi = the MFMA-row deal that gives a
   // lane 8 consecutive channels over a pair of channel tiles (tile 2p row 4q+j -> channel 32p + 8q + j, tile 2p+1 -> +4)
   uint32_t woff[NWI];
-  const int cgw_x = (lane & 7);
+  // chunk column of this lane's weight DMAs: (r>>1)&7 with r = 8*(wave+4i) + (lane>>3) does not depend on i
+  const int cgw = (lane & 7) ^ ((((8 * wave + (lane >> 3)) >> 1)) & 7);
+  auto set_w = [&](int n0) {
 #pragma unroll
-  for (int i = 0; i < NWI; ++i) {
-    const int r = 8 * (wave + 4 * i) + (lane >> 3);
-    const int ti = r >> 4, rho = r & 15;
-    const int ch = (ti < 2 * NPAIR) ? 32 * (ti >> 1) + 8 * (rho >> 2) + 4 * (ti & 1) + (rho & 3) : r;
-    const int cg = cgw_x ^ ((r >> 1) & 7);
-    const int n = n0 + ch;
-    woff[i] = (r < BN && n < a.cout) ? (uint32_t)(n * a.kpad * ES + cg * 16) : kOob;
-  }
-  // chunk validity of this lane's weight chunk column is the same for all i:  (r>>1)&7 varies with i only through
-  // 8*(wave+4i) -> (4*(wave+4i))&7 = 4*(wave&1): constant over i
-  const int cgw = cgw_x ^ ((((8 * wave + (lane >> 3)) >> 1)) & 7);
-
+    for (int i = 0; i < NWI; ++i) {
+      const int r = 8 * (wave + 4 * i) + (lane >> 3);
+      const int ti = r >> 4, rho = r & 15;
+      const int ch = (ti < 2 * NPAIR) ? 32 * (ti >> 1) + 8 * (rho >> 2) + 4 * (ti & 1) + (rho & 3) : r;
+      const int n = n0 + ch;
+      woff[i] = (r < BN && n < a.cout) ? (uint32_t)(n * a.kpad * ES + cgw * 16) : kOob;
+    }
+  };
   auto issue_w = [&](int c, int tap, int slot) {
-    const uint32_t st = lds_base + (uint32_t)(g.slab_bytes + slot * WSLOT + wave * 1024);
+    const uint32_t st = lds_base + (uint32_t)(SLAB + slot * WSLOT + wave * 1024);
     const uint32_t kofs = (uint32_t)((tap * a.cin + c * CPR) * ES);
     const uint32_t inv = ((c * CPR + cgw * CE) < a.cin) ? 0u : kOob;
 #pragma unroll
     for (int i = 0; i < NWI; ++i) lds_dma16(rsw, st + i * 4096, (woff[i] + kofs) | inv);
   };
 
-  // ---- halo slab DMA: wave w fills halo rows w, w+4, ...; instruction (hy, gx) = LDS rows hy*HP + 8*gx .. +7
+  // ---- halo slab DMA: wave w fills halo rows w, w+4, ...; instruction (hy, gx) = LDS rows hy*HP + 8*gx .. +7, halo
+  // pixel hx = 8*gx + (lane>>3); the 16-byte slot s of a row holds channel chunk s ^ f(hx), f(h) = (h>>1)&7 - a swizzle
+  // by the COLUMN of the halo pixel, so a tap's row offset (dy*HP + dx) moves the address by a constant per dx
+  const int cg0 = (lane & 7) ^ (lane >> 4);                  // chunk of this lane for even gx; odd gx: ^4
   const int hxl = lane >> 3;
-  auto issue_slab = [&](int c) {
-    for (int hy = wave; hy < g.TH + 2; hy += 4) {
-      const int y = y0 - 1 + hy;
-      const bool yok = (y >= 0) && (y < H);
-      const int rowb = ((int)bimg * H + y) * W;             // pixel index of (y, 0)
-      const int swy = (hy * (g.HP >> 1)) & 7;
-      for (int gx = 0; gx < g.GX; ++gx) {
-        const int hx = gx * 8 + hxl;
-        const int x = x0 - 1 + hx;
-        const int cg = (lane & 7) ^ ((swy + (hx >> 1)) & 7);
-        const bool ok = yok && (x >= 0) && (x < W) && (hx < g.TW + 2) && ((c * CPR + cg * CE) < a.cin);
-        const uint32_t off = ok ? (uint32_t)((rowb + x) * ldB + (a.src[0].ch_off + c * CPR) * ES + cg * 16) : kOob;
-        lds_dma16(rs0, lds_base + (uint32_t)((hy * g.HP + gx * 8) * ROW_BYTES), off);
+  const int32_t lc0 = hxl * ldB + a.src[0].ch_off * ES + cg0 * 16;          // lane part of the source offset, even / odd gx
+  const int32_t lc1 = hxl * ldB + a.src[0].ch_off * ES + (cg0 ^ 4) * 16;
+  // per-lane, tile-dependent part (computed once per workgroup): bit gx of xmask = halo column hx = 8*gx + hxl is
+  // inside the image and inside the halo
+  uint32_t xmask = 0;
+  auto set_x = [&](int x0) {
+#pragma unroll
+    for (int gx = 0; gx < GX; ++gx) {
+      const int hx = gx * 8 + hxl, x = x0 - 1 + hx;
+      xmask |= (x >= 0 && x < W && hx < TW + 2) ? (1u << gx) : 0u;
+    }
+  };
+  auto issue_slab = [&](const Tile& t, int c) {
+    // chunk validity folded into the column masks (even / odd gx use different chunk columns)
+    const uint32_t m0_ = ((c * CPR + cg0 * CE) < a.cin) ? 0x55555555u : 0u, m1_ = ((c * CPR + (cg0 ^ 4) * CE) < a.cin) ? 0xAAAAAAAAu : 0u;
+    const uint32_t msk = xmask & (m0_ | m1_);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int hy = wave + 4 * i;
+      if (hy < TH + 2) {                                                        // wave-uniform; false only in the last round
+        const int y = t.y0 - 1 + hy;
+        const bool yok = (y >= 0) && (y < H);
+        const int32_t sb = ((t.bimg * H + y) * W + t.x0 - 1) * ldB + c * ROW_BYTES;
+        const uint32_t st = lds_base + (uint32_t)(hy * HP * ROW_BYTES);
+        const uint32_t mrow = yok ? msk : 0u;
+#pragma unroll
+        for (int gx = 0; gx < GX; ++gx) {
+          const uint32_t off = (uint32_t)(((gx & 1) ? lc1 : lc0) + sb + gx * 8 * ldB);
+          lds_dma16(rs0, st + gx * 1024, ((mrow >> gx) & 1u) ? off : kOob);
+        }
       }
     }
   };
 
-  // ---- per-lane fragment addresses and output pixels
+  // ---- per-lane fragment addresses (tile independent)
   uint32_t baddr[TPW][3];
-  int32_t mpix[TPW];                     // output pixel index (b*H + y)*W + x, or -1
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
     const int p = (wave * TPW + j) * 16 + frow;
-    const bool pv = p < g.npx;
+    const bool pv = p < NPX;
     const uint32_t pp = pv ? (uint32_t)p : 0u;
-    const int py = (int)magic_div(pp, g.mg_tw_mul, g.mg_tw_shift);
-    const int px = (int)pp - py * g.TW;
-    const int rb = py * g.HP + px;
+    const int py = (int)(pp / (uint32_t)TW);
+    const int px = (int)pp - py * TW;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      const int r = rb + dx;
-      baddr[j][dx] = (uint32_t)(r * ROW_BYTES + ((fq ^ ((r >> 1) & 7)) << 4));
+      const int hx = px + dx;
+      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ ((hx >> 1) & 7)) << 4));
     }
-    const int y = y0 + py, x = x0 + px;
-    mpix[j] = (pv && y < H && x < W) ? ((int)bimg * H + y) * W + x : -1;
   }
   const uint32_t aaddr = lds_off(frow, fq);
 
-  // ---- accumulators start at the bias
   f32x4 acc[TC][TPW];
-  {
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, g.bias_bytes, 0x00020000);
+  auto init_acc = [&](int n0) {          // accumulators start at the bias
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
       const int ch = (i < 2 * NPAIR) ? 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : 16 * i + 4 * fq;
-      const v4ie_t bv = __builtin_amdgcn_raw_buffer_load_b128(rb, (uint32_t)((n0 + ch) * 4), 0, 0);
+      const v4ie_t bv = __builtin_amdgcn_raw_buffer_load_b128(rbias, (uint32_t)((n0 + ch) * 4), 0, 0);
       const f32x4 bf = {__int_as_float(bv[0]), __int_as_float(bv[1]), __int_as_float(bv[2]), __int_as_float(bv[3])};
 #pragma unroll
       for (int j = 0; j < TPW; ++j) acc[i][j] = bf;
     }
-  }
+  };
 
-  auto compute = [&](auto dy_tag, auto dx_tag, int slot, bool full) __attribute__((always_inline)) {
-    constexpr int dy = decltype(dy_tag)::value, dx = decltype(dx_tag)::value;
-    const unsigned char* ws = smem + g.slab_bytes + slot * WSLOT;
-    const unsigned char* xs = smem + dy * g.HP * ROW_BYTES;
-    const uint32_t fl = (g.flip & dy & 1) ? 64u : 0u;
+  auto compute = [&](int dyoff, auto dx_tag, int slot, bool full) __attribute__((always_inline)) {
+    constexpr int dx = decltype(dx_tag)::value;
+    const unsigned char* ws = smem + SLAB + slot * WSLOT;
+    const unsigned char* xs = smem + dyoff;              // dy * HP * 128: the tap's row offset into the slab
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk == 1 && !full) break;                     // tail chunk with <= half a row of channels (wave-uniform)
@@ -172,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 #pragma unroll
       for (int i = 0; i < TC; ++i) af[i] = *reinterpret_cast<const uint4*>(ws + (aaddr ^ (uint32_t)(kk << 6)) + i * 16 * ROW_BYTES);
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ ((uint32_t)(kk << 6) ^ fl)));
+      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6)));
 #pragma unroll
       for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -180,115 +214,187 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
     }
   };
 
-  // ---- K loop: chunk outermost; per tap one barrier, the next tap's weights in flight under this tap's MFMAs
-  issue_slab(0);
-  issue_w(0, 0, 0);
-  int slot = 0;
-  for (int c = 0; c < g.nchunk; ++c) {
-    const bool full = (a.cin - c * CPR) > CPR / 2;
-    const bool more = (c + 1 < g.nchunk);
-#define MIYOLO_H2_TAP(T_, DY, DX)                                                                   \
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                   \
-    if ((T_) < 8) issue_w(c, (T_) + 1, slot ^ 1); else if (more) issue_w(c + 1, 0, slot ^ 1);       \
-    compute(std::integral_constant<int, DY>{}, std::integral_constant<int, DX>{}, slot, full);      \
-    slot ^= 1;
-    MIYOLO_H2_TAP(0, 0, 0) MIYOLO_H2_TAP(1, 0, 1) MIYOLO_H2_TAP(2, 0, 2)
-    MIYOLO_H2_TAP(3, 1, 0) MIYOLO_H2_TAP(4, 1, 1) MIYOLO_H2_TAP(5, 1, 2)
-    MIYOLO_H2_TAP(6, 2, 0) MIYOLO_H2_TAP(7, 2, 1) MIYOLO_H2_TAP(8, 2, 2)
-#undef MIYOLO_H2_TAP
-    if (more) {
-      asm volatile("s_barrier" ::: "memory");          // every wave is done with the slab
-      issue_slab(c + 1);
-    }
-  }
-
-  // ---- epilogue: activation, residual, 8 channels per store
-  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.dst), 0, a.res ? a.res_bytes : 0u, 0x00020000);
   auto act = [&](float x) -> float {
     if (!a.act) return x;
     if constexpr (ES == 4) return silu_exact(x); else return silu_fast(x);
   };
+
+#if MIYOLO_ABLATE
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s_begin = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, acc_slab = 0, acc_slabbar = 0, acc_epi = 0, n_tiles = 0;
+  STAMP(s_begin);
+#define H2_ACC acc_wait += s1 - s0; acc_issue += s2 - s1; acc_comp += s3 - s2;
+#else
+#define H2_ACC
+#endif
+
+  // ---- K loop: chunk outermost; per tap one barrier, the next tap's weights in flight under this tap's MFMAs
+  const Tile cur = tile_coords(L);
+  set_w(cur.n0);
+  set_x(cur.x0);
+#if MIYOLO_ABLATE
+  unsigned long long p0 = 0, p1 = 0, p2 = 0;
+  STAMP(p0);
+#endif
+  issue_slab(cur, 0);
+  issue_w(0, 0, 0);
+  STAMP(p1);
+  init_acc(cur.n0);
+#if MIYOLO_ABLATE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(p2);
+#endif
+  int slot = 0;
+  {
+    // The tap loop is a real loop over dy with dx unrolled - NOT nine unrolled taps: the fully unrolled kernel was 60-80 KB
+    // of code for an instruction cache of 64 KB shared by two CUs (four resident workgroups at different places of it),
+    // and every layer ran 10-15 % slower than with a third of the code.
+    for (int c = 0; c < g.nchunk; ++c) {
+      const bool full = (a.cin - c * CPR) > CPR / 2;
+      const bool more = (c + 1 < g.nchunk);
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy) {
+        const int dyoff = dy * HP * ROW_BYTES;
+#define MIYOLO_H2_TAP(DX)                                                                           \
+        STAMP(s0);                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                               \
+        STAMP(s1);                                                                                  \
+        if (dy * 3 + (DX) < 8) issue_w(c, dy * 3 + (DX) + 1, slot ^ 1);                             \
+        else if (more) issue_w(c + 1, 0, slot ^ 1);                                                 \
+        STAMP(s2);                                                                                  \
+        compute(dyoff, std::integral_constant<int, DX>{}, slot, full);                              \
+        STAMP(s3);                                                                                  \
+        H2_ACC                                                                                      \
+        slot ^= 1;
+        MIYOLO_H2_TAP(0) MIYOLO_H2_TAP(1) MIYOLO_H2_TAP(2)
+#undef MIYOLO_H2_TAP
+      }
+      if (more) {
+        STAMP(s0);
+        asm volatile("s_barrier" ::: "memory");        // every wave is done with the slab
+        STAMP(s5);
+        if (!ABL(1)) issue_slab(cur, c + 1);
+        STAMP(s1);
+#if MIYOLO_ABLATE
+        acc_slab += s1 - s5; acc_slabbar += s5 - s0;
+#endif
+      }
+    }
+    STAMP(s4);
+
+    // ---- epilogue (activation, residual, 8 channels per store)
+    int32_t mpix[TPW];
 #pragma unroll
-  for (int ip = 0; ip < NPAIR; ++ip) {
-    const int n = n0 + 32 * ip + 8 * fq;
-    const bool nok = n < a.cout;
-    v4ie_t r0[TPW], r1[TPW];
-    if (a.res) {
+    for (int j = 0; j < TPW; ++j) {
+      const int p = (wave * TPW + j) * 16 + frow;
+      const int py = (int)((uint32_t)p / (uint32_t)TW);
+      const int y = cur.y0 + py, x = cur.x0 + p - py * TW;
+      mpix[j] = (p < NPX && y < H && x < W) ? (cur.bimg * H + y) * W + x : -1;
+    }
+#pragma unroll
+    for (int ip = 0; ip < NPAIR; ++ip) {
+      const int n = cur.n0 + 32 * ip + 8 * fq;
+      const bool nok = n < a.cout;
+      v4ie_t r0[TPW], r1[TPW];
+      if constexpr (ES == 2) {
+        if (a.res) {                     // f16: the four residual loads of a channel pair in flight together
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+            r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
-        r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
-        if constexpr (ES == 4) r1[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 16);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v[r] = act(acc[2 * ip][j][r]); v[4 + r] = act(acc[2 * ip + 1][j][r]); }
-      if (a.res) {
         if constexpr (ES == 4) {
+          if (a.res) {                   // f32 (parity mode): one pixel at a time keeps the register count down
+            const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+            r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+            r1[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro + 16u, 0, 0);
+          }
+        }
+        float v[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { v[r] += __int_as_float(r0[j][r]); v[4 + r] += __int_as_float(r1[j][r]); }
+        for (int r = 0; r < 4; ++r) { v[r] = act(acc[2 * ip][j][r]); v[4 + r] = act(acc[2 * ip + 1][j][r]); }
+        if (a.res) {
+          if constexpr (ES == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += __int_as_float(r0[j][r]); v[4 + r] += __int_as_float(r1[j][r]); }
+          } else {
+            const f16x8 hr = *reinterpret_cast<const f16x8*>(&r0[j]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
+          }
+        }
+        const uint32_t so = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
+        if constexpr (ES == 4) {
+          const v4ie_t o0 = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+          const v4ie_t o1 = {__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o1, rdst, so + 16u, 0, 0);
         } else {
-          const f16x8 hr = *reinterpret_cast<const f16x8*>(&r0[j]);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
+          const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, 0);
         }
       }
-      const uint32_t so = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
-      if constexpr (ES == 4) {
-        const v4ie_t o0 = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
-        const v4ie_t o1 = {__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, rdst, so, 0, 16);
-      } else {
-        const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, 0);
-      }
     }
-  }
-  if constexpr (TC & 1) {                                // unpaired last channel tile: 4 channels per lane
-    constexpr int i = TC - 1;
-    const int n = n0 + 16 * i + 4 * fq;
-    const bool nok = n < a.cout;
+    if constexpr (TC & 1) {                              // unpaired last channel tile: 4 channels per lane
+      constexpr int i = TC - 1;
+      const int n = cur.n0 + 16 * i + 4 * fq;
+      const bool nok = n < a.cout;
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      float v[4];
+      for (int j = 0; j < TPW; ++j) {
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = act(acc[i][j][r]);
-      const bool ok = nok && mpix[j] >= 0;
-      if (a.res) {
-        const uint32_t ro = ok ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+        for (int r = 0; r < 4; ++r) v[r] = act(acc[i][j][r]);
+        const bool ok = nok && mpix[j] >= 0;
+        if (a.res) {
+          const uint32_t ro = ok ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+          if constexpr (ES == 4) {
+            const v4ie_t rr = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += __int_as_float(rr[r]);
+          } else {
+            const v2i_t rr = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
+            const f16x4 hr = *reinterpret_cast<const f16x4*>(&rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)hr[r];
+          }
+        }
+        const uint32_t so = ok ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
         if constexpr (ES == 4) {
-          const v4ie_t rr = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += __int_as_float(rr[r]);
+          const v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
         } else {
-          const v2i_t rr = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
-          const f16x4 hr = *reinterpret_cast<const f16x4*>(&rr);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)hr[r];
+          const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
         }
       }
-      const uint32_t so = ok ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
-      if constexpr (ES == 4) {
-        const v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
-      } else {
-        const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
-      }
     }
+    STAMP(s5);
+#if MIYOLO_ABLATE
+    acc_epi += s5 - s4; n_tiles = 1;
+#endif
   }
+#undef H2_ACC
+#if MIYOLO_ABLATE
+  if (a.dbg && lane == 0 && blockIdx.x < 512) {      // per wave: total, wait, issue, compute, slab, epilogue cycles
+    STAMP(s5);
+    unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+    d[0] = s5 - s_begin; d[1] = acc_wait; d[2] = acc_issue; d[3] = acc_comp; d[4] = acc_slab; d[5] = acc_epi;
+    d[6] = (unsigned long long)g.nchunk * 9 * n_tiles; d[7] = acc_slabbar + 1;
+    unsigned long long* e = a.dbg + 16384 + ((size_t)blockIdx.x * 4 + wave) * 4;
+    e[0] = p0 - s_begin; e[1] = p1 - p0; e[2] = p2 - p1; e[3] = s_begin;
+  }
+#endif
 }
 
 // host side ------------------------------------------------------------------------------------------------------
 template <int TC> constexpr size_t h2_wring_bytes() { return (size_t)2 * ((TC * 16 + 31) / 32 * 32) * ROW_BYTES; }
 
-inline int h2_pick_tc(int cout) {
+inline int h2_pick_tc(int cout, int elem = 2) {
   // channel tile: 96 where it divides or the tail is small, else 64 / 48
+  if (elem == 4) return (cout % 48 == 0 || cout <= 48) ? 3 : (cout % 64 == 0 || cout <= 64) ? 4 : 3;   // fp32 (parity mode): 96-channel tiles spill
   if (cout <= 48) return 3;
   if (cout <= 64) return 4;
   if (cout % 96 == 0) return 6;
@@ -296,39 +402,39 @@ inline int h2_pick_tc(int cout) {
   return 6;
 }
 
-// Tile geometry for an H x W map: the TW x TH (TH = 256 / TW) shape with the best pixel utilisation whose slab fits.
-inline bool h2_shape(int cin, int cout, int B, int H, int W, int elem, int ce, int tc, H2Geom* g, size_t* lds) {
-  static const int cands[] = {16, 32, 20, 40, 8, 12, 24, 48, 64, 80, 10};
+// Tile geometry for an H x W map: the compiled TW x TH shape with the best pixel utilisation.
+inline bool h2_shape(int cin, int cout, int B, int H, int W, int elem, int ce, int tc, H2Geom* g, size_t* lds, int* geo) {
   const size_t wring = (size_t)2 * ((tc * 16 + 31) / 32 * 32) * ROW_BYTES;
   double best = -1.0;
-  int btw = 0;
-  for (int tw : cands) {
-    if (tw > ((W + 7) / 8 * 8) && tw != 8) continue;
-    const int th = 256 / tw;
-    const int hp = (tw + 2 + 7) / 8 * 8;
+  int bgeo = -1;
+  for (int ge = 0; ge < 3; ++ge) {
+    int tw, th, hp;
+    h2_geo(ge, &tw, &th, &hp);
     const size_t need = (size_t)(th + 2) * hp * ROW_BYTES + wring;
     if (need > (size_t)kH2LdsMax) continue;
     const double tiles = (double)((W + tw - 1) / tw) * ((H + th - 1) / th);
     const double util = (double)W * H / (tiles * 256.0);
-    const double fillrows = (double)(th + 2) * ((tw + 2 + 7) / 8) * 8;
-    const double score = util - 1e-4 * fillrows / 256.0;          // ties: the smaller halo
-    if (score > best) { best = score; btw = tw; }
+    const double score = util - 1e-3 * ge;                           // ties: the 16 x 16 tile
+    if (score > best) { best = score; bgeo = ge; }
   }
-  if (btw == 0) return false;
+  if (bgeo < 0) return false;
   const int cpr = 8 * ce;
-  g->TW = btw; g->TH = 256 / btw; g->HP = (btw + 2 + 7) / 8 * 8; g->GX = (btw + 2 + 7) / 8;
+  h2_geo(bgeo, &g->TW, &g->TH, &g->HP);
+  g->GX = (g->TW + 2 + 7) / 8;
   g->tiles_x = (W + g->TW - 1) / g->TW; g->tiles_y = (H + g->TH - 1) / g->TH; g->NB = (cout + tc * 16 - 1) / (tc * 16);
   g->ntiles = B * g->tiles_x * g->tiles_y * g->NB;
   g->nchunk = (cin + cpr - 1) / cpr;
   g->npx = g->TH * g->TW;
   g->slab_bytes = (g->TH + 2) * g->HP * ROW_BYTES;
-  g->flip = (g->HP % 16) == 8;
   host_magic((uint32_t)g->TW, &g->mg_tw_mul, &g->mg_tw_shift);
   host_magic((uint32_t)g->NB, &g->mg_nb_mul, &g->mg_nb_shift);
   host_magic((uint32_t)g->tiles_x, &g->mg_tx_mul, &g->mg_tx_shift);
   host_magic((uint32_t)g->tiles_y, &g->mg_ty_mul, &g->mg_ty_shift);
   g->bias_bytes = (uint32_t)((cout + 127) / 128 * 128 * 4);
+  g->scratch_off = (g->TW + 2) * ROW_BYTES;          // halo row 0, columns beyond the halo: never read (>= 256 B in every geometry)
+  g->warm = 1;
   *lds = (size_t)g->slab_bytes + wring;
+  *geo = bgeo;
   (void)elem;
   return true;
 }
@@ -338,7 +444,7 @@ inline double h2_util(const H2Geom& g, int H, int W) {
 }
 
 template <typename T>
-inline bool h2_geometry(const ConvArgs& a, H2Geom* g, size_t* lds, int* tc) {
+inline bool h2_geometry(const ConvArgs& a, H2Geom* g, size_t* lds, int* tc, int* geo) {
   constexpr int ES = (int)sizeof(T);
   if (a.ksize != 3 || a.stride != 1 || a.nsrc != 1 || a.src[0].up || a.out_f32) return false;
   if (a.Hin != a.Hout || a.Win != a.Wout) return false;
@@ -346,24 +452,36 @@ inline bool h2_geometry(const ConvArgs& a, H2Geom* g, size_t* lds, int* tc) {
   if (a.cout % 8 || a.dst_ld % 8 || a.dst_choff % 8) return false;                 // 8-channel stores
   if (a.res && (a.res_ld % 8 || a.res_choff % 8)) return false;
   if ((long)a.B * a.Hin * a.Win * a.src[0].ld * ES >= (1l << 31)) return false;
-  *tc = h2_pick_tc(a.cout);
-  return h2_shape(a.cin, a.cout, a.B, a.Hout, a.Wout, ES, DT<T>::CE, *tc, g, lds);
+  *tc = h2_pick_tc(a.cout, ES);
+  return h2_shape(a.cin, a.cout, a.B, a.Hout, a.Wout, ES, DT<T>::CE, *tc, g, lds, geo);
 }
 
 template <typename T>
 inline bool h2_eligible(const ConvArgs& a, double min_util) {
-  H2Geom g; size_t lds; int tc;
-  return h2_geometry<T>(a, &g, &lds, &tc) && h2_util(g, a.Hout, a.Wout) >= min_util;
+  H2Geom g; size_t lds; int tc, geo;
+  return h2_geometry<T>(a, &g, &lds, &tc, &geo) && h2_util(g, a.Hout, a.Wout) >= min_util;
+}
+
+template <typename T, int TC>
+inline void launch_h2_geo(const ConvArgs& a, const H2Geom& g, int geo, size_t lds, hipStream_t s) {
+  const dim3 grid((unsigned)g.ntiles), blk(256);
+  switch (geo) {
+    case 1: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 1>), grid, blk, lds, s, a, g); break;
+    case 2: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 2>), grid, blk, lds, s, a, g); break;
+    default: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 0>), grid, blk, lds, s, a, g); break;
+  }
 }
 
 template <typename T>
-inline hipError_t launch_conv_h2(const ConvArgs& a, hipStream_t s) {
-  H2Geom g; size_t lds; int tc;
-  if (!h2_geometry<T>(a, &g, &lds, &tc)) return hipErrorInvalidValue;
+inline hipError_t launch_conv_h2(const ConvArgs& a, hipStream_t s, int ncu, int warm = 1) {
+  H2Geom g; size_t lds; int tc, geo;
+  if (!h2_geometry<T>(a, &g, &lds, &tc, &geo)) return hipErrorInvalidValue;
+  g.warm = warm;
+  (void)ncu;
   switch (tc) {
-    case 3: hipLaunchKernelGGL((conv_h2_kernel<T, 3>), dim3((unsigned)g.ntiles), dim3(256), lds, s, a, g); break;
-    case 4: hipLaunchKernelGGL((conv_h2_kernel<T, 4>), dim3((unsigned)g.ntiles), dim3(256), lds, s, a, g); break;
-    default: hipLaunchKernelGGL((conv_h2_kernel<T, 6>), dim3((unsigned)g.ntiles), dim3(256), lds, s, a, g); break;
+    case 3: launch_h2_geo<T, 3>(a, g, geo, lds, s); break;
+    case 4: launch_h2_geo<T, 4>(a, g, geo, lds, s); break;
+    default: launch_h2_geo<T, 6>(a, g, geo, lds, s); break;
   }
   return hipGetLastError();
 }
@@ -371,10 +489,11 @@ inline hipError_t launch_conv_h2(const ConvArgs& a, hipStream_t s) {
 template <typename T>
 inline hipError_t set_h2_attrs() {
   hipError_t e;
-#define MIYOLO_H2_ATTR(TC)                                                                              \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<T, TC>),                    \
+#define MIYOLO_H2_ATTR(TC, GEO)                                                                         \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<T, TC, GEO>),               \
                                hipFuncAttributeMaxDynamicSharedMemorySize, kH2LdsMax)) != hipSuccess) return e;
-  MIYOLO_H2_ATTR(3) MIYOLO_H2_ATTR(4) MIYOLO_H2_ATTR(6)
+  MIYOLO_H2_ATTR(3, 0) MIYOLO_H2_ATTR(4, 0) MIYOLO_H2_ATTR(6, 0) MIYOLO_H2_ATTR(3, 1) MIYOLO_H2_ATTR(4, 1) MIYOLO_H2_ATTR(6, 1)
+  MIYOLO_H2_ATTR(3, 2) MIYOLO_H2_ATTR(4, 2) MIYOLO_H2_ATTR(6, 2)
 #undef MIYOLO_H2_ATTR
   return hipSuccess;
 }

@@ -68,6 +68,7 @@ struct miyolo_engine {
   int dmh_auto = 0;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h); off since the
                             // balanced grids: +0.2 % without it (same-box A/B), it won only by removing a half-empty round
   int h2 = 1;               // conv_impl 3: 3x3 stride-1 layers on the halo-slab kernel (conv_h2.h) where its tiles cover the map well
+  int h2_warm = 1;          // ... with the L2 warm-up of the next channel chunk's slab
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
@@ -359,10 +360,10 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
-      if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s));
+      if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
       else if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && t2d_eligible<T>(a))
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
-      else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) HIP_TRY(h, launch_conv_h2<T>(a, s));
+      else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
 #if MIYOLO_EXPERIMENTS
       else if ((h->conv_impl == 6 || (h->conv_impl == 3 && h->dmh_auto && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
         HIP_TRY(h, launch_conv_dmh<T>(a, s, h->ncu, h->force_wc, h->force_tc));
@@ -437,9 +438,9 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
                    t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
   const bool s1 = op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample && ob.dtype != MIYOLO_F32 && op.cout % 8 == 0;
   if (s1 && (h->conv_impl == 8 || (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && !t2d))) {
-    H2Geom hg; size_t hl;
-    const int es = h->desc.dtype == MIYOLO_F16 ? 2 : 4, tc = h2_pick_tc(op.cout);
-    if (h2_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, es, 16 / es, tc, &hg, &hl) &&
+    H2Geom hg; size_t hl; int hgeo;
+    const int es = h->desc.dtype == MIYOLO_F16 ? 2 : 4, tc = h2_pick_tc(op.cout, es);
+    if (h2_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, es, 16 / es, tc, &hg, &hl, &hgeo) &&
         (h->conv_impl == 8 || h2_util(hg, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h2_min_util))
       return 8000 + 300 + 40 + tc;                          // conv_h2_kernel<T,TC>
   }
@@ -646,6 +647,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
+  if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }
   if (!strcmp(key, "h2_min_util")) { h->h2_min_util = value; return 0; }
   if (!strcmp(key, "dmh_auto")) { h->dmh_auto = value; return 0; }
   if (!strcmp(key, "ncu")) { if (value < 8 || value > 1024) return fail(h, MIYOLO_ERR_ARG, "ncu out of range"); h->ncu = value; return 0; }   // persistent-grid width (A/B)

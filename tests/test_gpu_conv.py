@@ -208,8 +208,10 @@ def test_t2d_kernel_shapes(dtype, cin, cout, H, W, B, res):
     y1 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=1)
     if dtype == "f32":
         assert np.array_equal(y7, y1)
-    y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=3)      # default engine: same kernel
+    y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=3, opts={"h2": 0})   # ring-kernel engine: same kernel
     assert np.array_equal(y3, y7)
+    yd = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=3)      # default engine (t2d where it fits, else the halo-slab kernel)
+    assert rel_err(yd, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
@@ -237,10 +239,10 @@ def test_t2d_channel_slices(dtype):
     (576, 64, 20, 20, 2, False),
     (64, 64, 20, 20, 2, False),       # one chunk exactly
     (96, 72, 68, 80, 1, True),        # letterboxed 544x640 frame: 68-wide map; channel tail (72 of 96)
-    (96, 96, 17, 20, 2, False),       # odd height
+    (96, 96, 18, 20, 2, False),       # partial tile rows
     (16, 16, 16, 16, 3, True),        # classifier sizes: a quarter chunk
     (32, 200, 12, 20, 2, False),      # cout 200 = 2 x 96 + 8
-    (24, 40, 9, 7, 5, True),          # tiny maps, several tiles idle rows/columns
+    (24, 40, 10, 6, 5, True),         # tiny maps, several tiles idle rows/columns
 ])
 def test_h2_kernel_shapes(dtype, cin, cout, H, W, B, res):
     """conv_h2.h (conv_impl 8, and the default engine where its tiles cover the map): slab pitch classes, partial tiles
