@@ -2,28 +2,30 @@
 """Headline benchmark: frames/s of yolov8m (nc=64) @ 640x640, batch 64 per GPU, NMS on-GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...;
+     without torchrun, `python bench.py --gpus N` spawns the N ranks itself)
 
 A "step" is one pass of the hot path over one batch of synthetic frames already resident in
-HBM: stem -> 82 MFMA convs -> SPPF pools -> Detect decode -> NMS -> (N>1) RCCL all-gather of the
-padded detections.  Rank 0 prints ONE JSON line (contract in the task statement), with
-`roofline` for the dominant kernel (per-launch HIP-event timings taken on the launch stream by
-the engine) and `cpu_baseline` (the CPU oracle = restated Ultralytics CPU path, timed on this
-host's cores on a bounded sample).
+HBM: stem -> 82 MFMA convs -> SPPF pools -> Detect decode -> NMS -> (N>1) one RCCL all-gather of
+the padded detections, issued on a side stream so that it overlaps the next batch.  Rank 0 prints
+ONE JSON line (contract in the task statement) with
+  roofline      the dominant kernel (per-launch HIP-event timings taken on the launch stream by the engine),
+  parity        the timed dtype's detections against the CPU oracle on a sample of the bench frames
+                ("mAP delta vs CPU ref" of BASELINE.json's metric: oracle detections are the ground truth),
+  exact_f32     a short timed loop of the exact-fp32 mode (the mode that meets north_star's identical-indices bar),
+  cpu_baseline  the CPU oracle (restated Ultralytics CPU path) timed on this host's cores, SURVEY.md 8d protocol.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f8": 5000.0}     # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
@@ -32,60 +34,279 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default 64 detect / 256 classify)")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--scale", default="m")
     ap.add_argument("--nc", type=int, default=64)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f8"])
     ap.add_argument("--workload", default="detect", choices=["detect", "classify"])
     ap.add_argument("--chunk", type=int, default=0, help="images per engine pass (0 = auto)")
-    ap.add_argument("--conv-impl", type=int, default=-1, help="0 register-staged conv, 1 LDS-DMA ring, 2 ring + halo kernel, 3 persistent ring, 4 persistent halo, 5 warp-specialised, 6 half-size stages x 2 workgroups per CU (default: engine default)")
-    ap.add_argument("--graph", type=int, default=-1, help="1: hipGraph replay of the step's launches (measured SLOWER: classifier 0.290 vs 0.230 ms per batch of 256, detect unchanged; default off)")
+    ap.add_argument("--conv-impl", type=int, default=-1, help="0 register-staged conv, 1 LDS-DMA ring, 3 engine default (persistent ring + halo-slab + 2-D-tile kernels), 7 / 8 force the 2-D-tile / halo-slab kernel where eligible")
+    ap.add_argument("--graph", type=int, default=-1, help="1: hipGraph replay of the step's launches (measured no gain; default off)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (miyolo_set_option), repeatable: A/B timing of kernel choices")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (wrong results): see common.h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true")
+    ap.add_argument("--parity-frames", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=50.0)
     ap.add_argument("--profile-out", default="")
     return ap.parse_args()
 
 
-def cpu_baseline(args, sd, meta, frames_np):
-    """Oracle (port of the Ultralytics CPU path) on the host cores, bounded sample."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start one child per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set),
+    relay rank 0's JSON line, fail if any rank fails.  The parent never initialises the GPU."""
+    import socket
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count()          # does not initialise the runtime
+    if have < n and not os.environ.get("MIYOLO_FORCE_DEVICE"):
+        print(f"[bench] --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0 if all(rc == 0 for rc in rcs) else 1
+
+
+# ----------------------------------------------------------------------------------------------- parity vs the oracle
+def _iou_matrix(a, b):
+    import numpy as np
+    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa[:, None] + ab[None, :] - inter + 1e-12)
+
+
+def map50_95(dets, gts):
+    """COCO-style mAP@[.5:.95] (101-point interpolation, per class, mean over classes with ground truth and over the
+    ten IoU thresholds) of `dets` (list per image of [n,6] x1,y1,x2,y2,conf,cls) against `gts` (same format: the CPU
+    oracle's detections are the ground truth).  Identical detections give exactly 1.0."""
+    import numpy as np
+    thr = np.arange(0.5, 0.96, 0.05)
+    classes = sorted({int(c) for g in gts for c in g[:, 5]})
+    aps = []
+    for c in classes:
+        recs = []                                     # (score, tp[10]) over all images
+        npos = 0
+        for d, g in zip(dets, gts):
+            dc, gc = d[d[:, 5] == c], g[g[:, 5] == c]
+            npos += len(gc)
+            if len(dc) == 0:
+                continue
+            order = np.argsort(-dc[:, 4], kind="stable")
+            dc = dc[order]
+            tp = np.zeros((len(dc), len(thr)), bool)
+            if len(gc):
+                iou = _iou_matrix(dc[:, :4], gc[:, :4])
+                for t, th in enumerate(thr):
+                    used = np.zeros(len(gc), bool)
+                    for i in range(len(dc)):
+                        j = int(np.argmax(np.where(used, -1.0, iou[i])))
+                        if not used[j] and iou[i, j] >= th:
+                            used[j] = True
+                            tp[i, t] = True
+            recs += [(dc[i, 4], tp[i]) for i in range(len(dc))]
+        if npos == 0:
+            continue
+        if not recs:
+            aps.append(0.0)
+            continue
+        recs.sort(key=lambda r: -r[0])
+        tpm = np.array([r[1] for r in recs], float)
+        ctp = np.cumsum(tpm, 0); cfp = np.cumsum(1 - tpm, 0)
+        rec = ctp / npos; prec = ctp / (ctp + cfp)
+        ap_t = []
+        grid = np.linspace(0, 1, 101)
+        for t in range(len(thr)):
+            mrec = np.concatenate(([0.0], rec[:, t], [1.0])); mpre = np.concatenate(([1.0], prec[:, t], [0.0]))
+            mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+            # precision at each recall grid point = max precision at recall >= r (COCO); 0 beyond the reached recall
+            idx = np.searchsorted(mrec, grid, side="left")
+            ap_t.append(float(np.mean(mpre[np.minimum(idx, len(mpre) - 1)])))
+        aps.append(float(np.mean(ap_t)))
+    return float(np.mean(aps)) if aps else 1.0
+
+
+def parity_block(eng, sd, meta, frames_np, nframes):
+    """Detections of the timed engine vs the CPU oracle (restated Ultralytics CPU path, fp32) on `nframes` bench frames."""
+    import numpy as np
+    import torch
     from oracle.post_ref import non_max_suppression
     from oracle.yolo_ref import RefYolo
-    # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
-    cores = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)
+    n = min(nframes, len(frames_np))
+    ref = RefYolo(sd, "detect", meta["nc"], meta["scale"], meta["bn_eps"], nc_quirk=meta.get("nc_quirk", True))
+    x = torch.from_numpy(frames_np[:n]).permute(0, 3, 1, 2).float() / 255
+    y = ref.forward(x)[0].numpy()
+    outs, idxs = non_max_suppression(y, 0.25, 0.7)
+    dets, counts, anchor = eng.detect(torch.from_numpy(frames_np[:n]).to(eng.device), 0.25, 0.7)
+    dets, counts, anchor = dets.cpu().numpy(), counts.cpu().numpy(), anchor.cpu().numpy()
+    got = [dets[b, :counts[b]] for b in range(n)]
+    ident = 0; common = 0; total = 0; mb = 0.0; ms = 0.0
+    for b in range(n):
+        ga = anchor[b, :counts[b]]
+        ident += int(len(ga) == len(idxs[b]) and np.array_equal(ga, idxs[b]))
+        cm, gi, oi = np.intersect1d(ga, idxs[b], return_indices=True)
+        common += len(cm); total += len(idxs[b])
+        if len(cm):
+            mb = max(mb, float(np.abs(got[b][gi, :4] - outs[b][oi, :4]).max()))
+            ms = max(ms, float(np.abs(got[b][gi, 4] - outs[b][oi, 4]).max()))
+    m = map50_95(got, outs)
+    return {"frames": n, "reference": "CPU oracle (restated Ultralytics CPU path, fp32) on the same frames; its detections are the ground truth",
+            "map50_95": round(m, 5), "map50_95_delta": round(1.0 - m, 5),
+            "kept_index_agreement": round(common / max(total, 1), 5), "frames_with_identical_kept_indices": f"{ident}/{n}",
+            "max_box_px": round(mb, 4), "max_score": round(ms, 6), "kept_boxes_reference": total}
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline (8d protocol)
+def cpu_baseline(args, sd, meta, frames_np):
+    """the torch-CPU restatement (fp32, BN folded) on this host's cores; B = 1 and B = 32 (detect),
+    3 warm-up + >= 10 timed iterations (bounded by --cpu-seconds), median; per-stage split."""
+    import numpy as np
+    import torch
+    from oracle.post_ref import non_max_suppression
+    from oracle.yolo_ref import RefYolo
+    cores = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)     # one GPU's share of the host
     torch.set_num_threads(cores)
     task = meta["task"]
     ref = RefYolo(sd, task, meta["nc"], meta["scale"], meta["bn_eps"], nc_quirk=meta.get("nc_quirk", True))
-    bs = 4 if task == "detect" else 256
-    x = torch.from_numpy(frames_np[:bs]).permute(0, 3, 1, 2).float() / 255
-    def once():
-        out = ref.forward(x)
-        if task == "detect":
-            non_max_suppression(out[0].numpy(), 0.25, 0.7)
-    once()
-    t0 = time.perf_counter(); n = 0
-    while True:
-        once(); n += 1
-        el = time.perf_counter() - t0
-        if el > args.cpu_seconds or n >= 50:
-            break
-    return {"value": round(bs * n / el, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} x batch {bs} of the same synthetic {x.shape[2]}x{x.shape[3]} frames, torch-CPU fp32 "
-                      f"restatement incl. NMS, {el:.1f} s"}
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    res = {}
+    t_budget = time.perf_counter() + args.cpu_seconds
+    for bs in ((1, 32) if task == "detect" else (1, 256)):
+        bs = min(bs, len(frames_np))
+        u8 = torch.from_numpy(frames_np[:bs])
+        stages = {"preprocess": [], "inference": [], "postprocess": []}
+        tot = []
+        it = 0
+        while it < 13 and (it < 5 or time.perf_counter() < t_budget):
+            t0 = time.perf_counter()
+            x = u8.permute(0, 3, 1, 2).float() / 255
+            t1 = time.perf_counter()
+            out = ref.forward(x)
+            t2 = time.perf_counter()
+            if task == "detect":
+                non_max_suppression(out[0].numpy(), 0.25, 0.7)
+            t3 = time.perf_counter()
+            if it >= 3:                                   # 3 warm-up iterations
+                stages["preprocess"].append(t1 - t0); stages["inference"].append(t2 - t1); stages["postprocess"].append(t3 - t2)
+                tot.append(t3 - t0)
+            it += 1
+        med = float(np.median(tot))
+        res[f"B{bs}"] = {"value": round(bs / med, 3), "iterations": len(tot),
+                         "ms_per_frame": {k: round(float(np.median(v)) * 1e3 / bs, 3) for k, v in stages.items()}}
+    big = res[sorted(res, key=lambda k: int(k[1:]))[-1]]
+    return {"value": big["value"], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": model,
+            "sample": f"torch-CPU fp32 restatement incl. NMS on the same synthetic frames, median of >= 10 timed iterations after 3 warm-up "
+                      f"(bounded by {args.cpu_seconds:.0f} s), per batch size", "by_batch": res}
+
+
+# ----------------------------------------------------------------------------------------------- roofline from engine events
+def kernel_name(cfg, kind, dtype):
+    if not cfg:
+        return {0: "stem", 2: "maxpool5", 3: "decode", 4: "cls_head"}.get(kind, "op")
+    fam = ("conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else
+           "conv_halop" if cfg >= 4000 else "conv_dmap" if cfg >= 3000 else "conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm")
+    return "%s<%s,k%d,wc%d,tc%d>" % (fam, dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)
+
+
+def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
+    import torch
+    eng.set_option("profile", 1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    recs = eng.profile_read()
+    eng.set_option("profile", 0)
+    chunk = eng.chunk(B, H, W)
+    per, perop = {}, {}
+    for op, cfg, ms in recs:
+        o = eng.prog.ops[op]
+        fl, by = eng.op_work(op, min(chunk, B), H, W)
+        e0 = perop.setdefault(op, {"name": o.name, "kind": o.kind, "k": o.ksize, "s": o.stride, "cin": o.cin, "cout": o.cout,
+                                   "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl, "bytes": by})
+        e0["n"] += 1; e0["ms"] += ms
+        e = per.setdefault(kernel_name(cfg, o.kind, dtype), [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
+    name, (n, ms, fl, by) = max(per.items(), key=lambda kv: kv[1][1])
+    # HBM traffic per launch of that kernel: not measurable from inside this process - taken from the committed
+    # rocprofv3 --pmc passes of the SAME workload (FETCH_SIZE x2 + WRITE_SIZE), with their provenance
+    traffic, tsrc = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
+        if key in tj["kernels"] and tj.get("workload") == [B, H, W, dtype]:
+            traffic = round(tj["kernels"][key]["traffic_bytes_per_launch"])
+            tsrc = "profiles/r02_traffic.json (rocprofv3 --pmc passes, committed; not re-measured by this run)"
+    except Exception:
+        pass
+    total_ms = sum(v[1] for v in per.values())
+    conv_fl = sum(v[2] for k, v in per.items() if k.startswith("conv")); conv_ms = sum(v[1] for k, v in per.items() if k.startswith("conv"))
+    if fl > 0:
+        ach = fl / (ms * 1e-3) / 1e12
+        rl = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+              "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "traffic_source": tsrc, "launches": n,
+              "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "algorithmic_bytes_per_launch": round(by / n),
+              "share_of_step_kernel_time": round(ms / total_ms, 3),
+              "all_convs_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None}
+    else:
+        ach = by / (ms * 1e-3) / 1e9
+        rl = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4)}
+    if profile_out:
+        with open(profile_out, "w") as f:
+            agg = {k: {"launches": v[0], "ms": v[1], "flop": v[2], "bytes": v[3], "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[1] else 0,
+                       "gbs": (v[3] / (v[1] * 1e-3) / 1e9) if v[1] else 0} for k, v in per.items()}
+            layers = []
+            for op in sorted(perop):
+                e0 = perop[op]
+                avg = e0["ms"] / e0["n"]
+                e0.update(avg_ms=avg, tflops=e0["flop"] / (avg * 1e-3) / 1e12 if avg else 0, gbs=e0["bytes"] / (avg * 1e-3) / 1e9 if avg else 0)
+                layers.append(e0)
+            json.dump({"by_kernel": agg, "by_op": layers}, f, indent=1)
+    return rl
+
+
+def model_roofline(eng, B, H, W, dtype, ms_per_step):
+    """layer-wise mixed roofline, t_min = sum over ops of max(flops / dense MFMA peak, compulsory bytes / HBM peak)."""
+    t_min = 0.0
+    for i in range(len(eng.prog.ops)):
+        fl_i, by_i = eng.op_work(i, B, H, W)
+        t_min += max(fl_i / (PEAK_TFLOPS[dtype] * 1e12), by_i / (HBM_PEAK_GBS * 1e9))
+    return t_min * 1e3, t_min * 1e3 / ms_per_step
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import numpy as np  # noqa: F401
+    import torch
     from manual_yolo_amd import dist as mdist
     from manual_yolo_amd.engine import engine_from_weights
     from manual_yolo_amd.synth import synth_frames, synth_meta, synth_state_dict
     rank, world, local = mdist.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if os.environ.get("MIYOLO_FORCE_DEVICE"):          # rehearsal: several ranks on one GPU (with gloo)
         local = int(os.environ["MIYOLO_FORCE_DEVICE"])
@@ -96,43 +317,51 @@ def main():
     if task == "detect":
         sd, meta = synth_state_dict("detect", args.nc, args.scale, 0), synth_meta("detect", args.nc, args.scale)
         H = W = args.imgsz
-        B = args.batch
+        B = args.batch or 64
     else:
         from manual_yolo_amd.ckpt import load_bundle
         sd, meta = load_bundle(os.path.join(ROOT, "tests", "golden", "rank_best.safetensors"))
         H = W = 64
-        B = args.batch if args.batch != 64 else 256
+        B = args.batch or 256
+    frames_np = synth_frames(B, H, W, seed=1 + rank)
+    frames = torch.from_numpy(frames_np).to(dev)
     eng = engine_from_weights(sd, meta, args.dtype, local, bgr_input=False)
-    if args.chunk:
-        eng.set_option("max_chunk", args.chunk)
-    if args.conv_impl >= 0:
-        eng.set_option("conv_impl", args.conv_impl)
-    if args.ablate:
-        eng.set_option("ablate", args.ablate)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        eng.set_option(k, int(v))
+
+    def tune(e):
+        if args.chunk:
+            e.set_option("max_chunk", args.chunk)
+        if args.conv_impl >= 0:
+            e.set_option("conv_impl", args.conv_impl)
+        if args.ablate:
+            e.set_option("ablate", args.ablate)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            e.set_option(k, int(v))
+    tune(eng)
     use_graph = args.graph if args.graph >= 0 else 0
     if use_graph:
         eng.set_option("graph", 1)
-    frames_np = synth_frames(B, H, W, seed=1 + rank)
-    frames = torch.from_numpy(frames_np).to(dev)
     max_det = 300
-    if task == "detect":
-        out = (torch.empty((B, max_det, 6), dtype=torch.float32, device=dev),
-               torch.empty((B,), dtype=torch.int32, device=dev), None)
-        gout = (torch.empty((world * B, max_det, 6), dtype=torch.float32, device=dev),
-                torch.empty((world * B,), dtype=torch.int32, device=dev)) if world > 1 else None
+    gather = mdist.DetectionGather(B, max_det, dev) if task == "detect" else None
+    kstep = [0]
 
     def step():
         if task == "detect":
-            d, c, _ = eng.detect(frames, 0.25, 0.7, False, max_det, None, want_anchor=False, out=out)
-            if world > 1:
-                mdist.all_gather_detections(d, c, out=gout)
+            k = kstep[0]; kstep[0] += 1
+            if k >= gather.depth:
+                gather.wait(k - gather.depth)          # the slot's previous gather is complete before it is overwritten
+            eng.detect(frames, 0.25, 0.7, False, max_det, None, want_anchor=False, out=gather.out_buffers(k))
+            gather.launch(k)                           # one message, on the side stream: overlaps the next batch
         else:
             eng.classify(frames)
 
+    def drain():
+        if task == "detect":
+            for k in range(max(0, kstep[0] - gather.depth), kstep[0]):
+                gather.wait(k)
+
     def barrier():
+        drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
@@ -144,92 +373,58 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0                   # host time to enqueue the K steps (Python + ctypes + launches)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_fps = [B * args.steps / elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        rank_fps = [B * args.steps / float(x.item()) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel: per-launch HIP events recorded by the engine
     roofline = None
     if not args.no_roofline:
-        eng.set_option("profile", 1)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        recs = eng.profile_read()
-        eng.set_option("profile", 0)
-        chunk = eng.chunk(B, H, W)
-        per = {}
-        perop = {}
-        for op, cfg, ms in recs:
-            o = eng.prog.ops[op]
-            fl0, by0 = eng.op_work(op, min(chunk, B), H, W)
-            e0 = perop.setdefault(op, {"name": o.name, "kind": o.kind, "k": o.ksize, "s": o.stride, "cin": o.cin, "cout": o.cout,
-                                       "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl0, "bytes": by0})
-            e0["n"] += 1; e0["ms"] += ms
-        for op, cfg, ms in recs:
-            k = ("%s<%s,k%d,wc%d,tc%d>" % ("conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else "conv_halop" if cfg >= 4000 else "conv_dmap" if cfg >= 3000 else "conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm", args.dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)) if cfg else \
-                {0: "stem", 2: "maxpool5", 3: "decode", 4: "cls_head"}.get(eng.prog.ops[op].kind, "op")
-            fl, by = eng.op_work(op, min(chunk, B), H, W)
-            e = per.setdefault(k, [0, 0.0, 0.0, 0.0])
-            e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
-        dom = max(per.items(), key=lambda kv: kv[1][1])
-        name, (n, ms, fl, by) = dom
-        # HBM traffic per launch of that kernel: not measurable from inside this process - taken from the
-        # committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json), same workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
-            key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
-            if key in tj and (B, H, W, args.dtype, args.scale) == (64, 640, 640, "f16", "m"):
-                traffic = round(tj[key]["traffic_bytes_per_launch"])
-        except Exception:
-            traffic = None
-        total_ms = sum(v[1] for v in per.values())
-        conv_fl = sum(v[2] for k, v in per.items() if k.startswith("conv")); conv_ms = sum(v[1] for k, v in per.items() if k.startswith("conv"))
-        if fl > 0:
-            ach = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype],
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                        "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
-                        "algorithmic_bytes_per_launch": round(by / n),
-                        "share_of_step_kernel_time": round(ms / total_ms, 3),
-                        "all_convs_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None}
-        else:
-            ach = by / (ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
-                        "avg_launch_ms": round(ms / n, 4)}
-        if args.profile_out and rank == 0:
-            with open(args.profile_out, "w") as f:
-                agg = {k: {"launches": v[0], "ms": v[1], "flop": v[2], "bytes": v[3],
-                           "tflops": (v[2] / (v[1] * 1e-3) / 1e12) if v[1] else 0,
-                           "gbs": (v[3] / (v[1] * 1e-3) / 1e9) if v[1] else 0} for k, v in per.items()}
-                layers = []
-                for op in sorted(perop):
-                    e0 = perop[op]
-                    avg = e0["ms"] / e0["n"]
-                    e0.update(avg_ms=avg, tflops=e0["flop"] / (avg * 1e-3) / 1e12 if avg else 0,
-                              gbs=e0["bytes"] / (avg * 1e-3) / 1e9 if avg else 0)
-                    layers.append(e0)
-                json.dump({"by_kernel": agg, "by_op": layers}, f, indent=1)
+        roofline = roofline_block(eng, step, args.steps, B, H, W, args.dtype, dev, args.profile_out if rank == 0 else "")
+        drain()
 
-    cpu = None
+    parity = exact = cpu = None
+    if rank == 0 and task == "detect" and not args.no_parity:
+        parity = parity_block(eng, sd, meta, frames_np, args.parity_frames)
+        parity["dtype"] = args.dtype
+    if rank == 0 and world == 1 and task == "detect" and args.dtype != "f32" and not args.no_exact_f32:
+        # the mode that meets north_star's "identical box indices after NMS": exact-fp32 MFMA chain, same workload
+        e32 = engine_from_weights(sd, meta, "f32", local, bgr_input=False)
+        tune(e32)
+        out32 = (torch.empty((B, max_det, 6), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev), None)
+        s32 = lambda: e32.detect(frames, 0.25, 0.7, False, max_det, None, want_anchor=False, out=out32)  # noqa: E731
+        for _ in range(2):
+            s32()
+        torch.cuda.synchronize(dev)
+        n32 = max(3, min(args.steps, 8))
+        t1 = time.perf_counter()
+        for _ in range(n32):
+            s32()
+        torch.cuda.synchronize(dev)
+        ms32 = (time.perf_counter() - t1) * 1e3 / n32
+        rl32 = roofline_block(e32, s32, 3, B, H, W, "f32", dev) if not args.no_roofline else None
+        tmin32, frac32 = model_roofline(e32, B, H, W, "f32", ms32)
+        exact = {"dtype": "f32", "value": round(B / ms32 * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms32, 3), "steps": n32,
+                 "model_roofline_frac": round(frac32, 4), "roofline": rl32}
+        if not args.no_parity:
+            p32 = parity_block(e32, sd, meta, frames_np, min(args.parity_frames, 4))
+            exact["parity"] = {k: p32[k] for k in ("frames", "map50_95_delta", "kept_index_agreement", "frames_with_identical_kept_indices", "max_box_px", "max_score")}
+        del e32
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sd, meta, frames_np)
+        cpu["gpu_over_cpu"] = round(value / cpu["value"], 1)
 
     if rank == 0:
         fl_step, by_step = eng.work(B, H, W)
-        # layer-wise mixed roofline of the whole step, t_min = sum over ops of
-        # max(flops / dense MFMA peak, compulsory bytes / HBM peak); model_roofline_frac = t_min / measured step
-        t_min = 0.0
-        for i in range(len(eng.prog.ops)):
-            fl_i, by_i = eng.op_work(i, B, H, W)
-            t_min += max(fl_i / (PEAK_TFLOPS[args.dtype] * 1e12), by_i / (HBM_PEAK_GBS * 1e9))
+        t_min_ms, mfrac = model_roofline(eng, B, H, W, args.dtype, ms_per_step)
         line = {
             "metric": "frames/sec whole-node, yolov8m@640 batch=64; mAP delta vs CPU ref" if task == "detect"
                       else "images/sec, yolov8n-cls rank classifier 64x64",
@@ -238,13 +433,15 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"yolov8{args.scale} detect nc={args.nc} {H}x{W}, batch {B}/GPU, seeded random-init "
                                     f"weights, uint8 frames resident in HBM, NMS on-GPU (conf 0.25, iou 0.7, max_det 300)"
-                                    + (", RCCL all-gather of detections" if world > 1 else ""))
+                                    + (", one RCCL all-gather of the padded detections per step on a side stream" if world > 1 else ""))
                                    if task == "detect" else f"yolov8n-cls rank_classifier weights 64x64, batch {B}/GPU",
                        "global_batch": world * B, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "gflop_per_frame": round(fl_step / B / 1e9, 3), "algorithmic_mb_per_frame": round(by_step / B / 1e6, 2),
                        "model_tflops": round(fl_step * world / (ms_per_step * 1e-3) / 1e12, 2),
-                       "model_t_min_ms": round(t_min * 1e3, 4), "model_roofline_frac": round(t_min * 1e3 / ms_per_step, 4)},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "model_t_min_ms": round(t_min_ms, 4), "model_roofline_frac": round(mfrac, 4),
+                       "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
+                       "per_rank_fps": [round(x, 1) for x in rank_fps]},
+            "roofline": roofline, "parity": parity, "exact_f32": exact, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

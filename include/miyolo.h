@@ -22,7 +22,8 @@
  *   - return value: 0 = OK, negative = miyolo_status; miyolo_last_error() gives the text.
  *     Nothing throws across the ABI.
  *   - a handle is bound to one device and is NOT re-entrant (one call in flight per
- *     handle); no global state, so one process per GPU or one handle per thread both work.
+ *     handle); no global state (the text of errors raised without a handle is thread-local), so one
+ *     process per GPU or one handle per thread both work.
  *   - activations are NHWC; the input image batch is uint8 NHWC with 3 channels in the
  *     channel order the packed stem weights expect (the Python host packs the stem for
  *     BGR frames, as the reference passes them).
@@ -120,6 +121,12 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
                   const void* const* weights, int device, miyolo_handle* out);
 void miyolo_destroy(miyolo_handle h);
 const char* miyolo_last_error(miyolo_handle h); /* h may be NULL: last create() error */
+
+/* Replaces: the `classes=` keyword of `model(frame, classes=[...])` ([3P] non_max_suppression(classes=...)): only
+ * candidates whose best class is in `classes` enter the sort / NMS / max_det steps (filter BEFORE NMS, as upstream).
+ * State of the handle, used by miyolo_detect and miyolo_nms until changed; n = 0 or classes = NULL removes the filter.
+ * Models with more than 256 classes: MIYOLO_ERR_UNSUPPORTED. */
+int miyolo_set_classes(miyolo_handle h, const int32_t* classes, int n);
 
 /* Bytes of scratch the caller must pass for a batch of B images of H x W pixels. */
 size_t miyolo_workspace_bytes(miyolo_handle h, int B, int H, int W);

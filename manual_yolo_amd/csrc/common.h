@@ -28,6 +28,10 @@ __device__ __forceinline__ P* sgpr_ptr(P* p) {
 }
 
 typedef _Float16 half_t;
+// fp8 e4m3 (OCP "fn": gfx950's native fp8, NOT MI300X's fnuz) activations / weights of the config-5 path: one byte per
+// element; conversions go through v_cvt_pk_fp8_f32 / v_cvt_f32_fp8, the arithmetic through the block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the f16 MFMA rate).
+struct fp8_t { unsigned char v; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -37,6 +41,21 @@ constexpr int kWave = 64;  // CDNA wavefront
 template <typename T> struct DT;
 template <> struct DT<float> { static constexpr int CE = 4; static constexpr int id = 0; };   // elems / 16 B chunk
 template <> struct DT<half_t> { static constexpr int CE = 8; static constexpr int id = 1; };
+template <> struct DT<fp8_t> { static constexpr int CE = 16; static constexpr int id = 2; };
+template <typename T> struct is_fp8 { static constexpr bool value = false; };
+template <> struct is_fp8<fp8_t> { static constexpr bool value = true; };
+
+// 4 floats -> 4 fp8 bytes (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN) and back
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), w, true);
+  return (uint32_t)w;
+}
+__device__ __forceinline__ void unpack_fp8x4(uint32_t w, float (&v)[4]) {
+  v[0] = __builtin_amdgcn_cvt_f32_fp8((int)w, 0); v[1] = __builtin_amdgcn_cvt_f32_fp8((int)w, 1);
+  v[2] = __builtin_amdgcn_cvt_f32_fp8((int)w, 2); v[3] = __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+}
 
 // SiLU exactly as torch computes it in fp32: x / (1 + exp(-x)).
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -79,6 +98,12 @@ struct ConvArgs {
   unsigned long long* dbg;          // MIYOLO_ABLATE builds: per-workgroup cycle stamps (conv_dmap.h)
   int32_t ablate;                   // timing experiments only (results wrong): 1 no tile DMA in the loop, 2 no MFMA, 4 no LDS reads
   int32_t exact;                    // 1: accurate expf in SiLU (fp32 parity mode)
+  // fp8 path: conv value = acc * qscale[n] (per-output-channel weight scale x the folded input scales) + bias[n];
+  // the stored activation is value(after SiLU, + res * res_scale) * out_inv_scale, rounded to e4m3.  `bias` points at
+  // bias[n] / qscale[n] for kernels that start their accumulators at it (conv_h2.h); bias_raw at the bias itself.
+  const float* qscale;
+  const float* bias_raw;
+  float out_inv_scale, res_scale;
 };
 
 // Shared conv epilogue tail: residual add (after the activation, as Bottleneck does) and the store
@@ -143,20 +168,22 @@ __device__ __forceinline__ v4ie_t epilogue_res_load(const ConvArgs& a, const __a
   const uint32_t ro = ok ? (uint32_t)((m * a.res_ld + a.res_choff + n) * (int)sizeof(T)) : 0x80000000u;
   if constexpr (sizeof(T) == 4) {
     return __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
-  } else {
+  } else if constexpr (sizeof(T) == 2) {
     const v2i_t r = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
     return (v4ie_t){r[0], r[1], 0, 0};
+  } else {
+    return (v4ie_t){__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0), 0, 0, 0};
   }
 }
 
 template <typename T, bool OUTF32>
 __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_buffer_rsrc_t& rdst, int m, int n,
-                                              const f32x4& acc, const float (&bv)[4], const v4ie_t& res) {
+                                              const f32x4& acc, const float (&bv)[4], const v4ie_t& res, const float (&sv)[4]) {
   const bool ok = (m < a.M) && (n < a.cout);
   float v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float x = acc[r] + bv[r];
+    float x = is_fp8<T>::value ? fmaf(acc[r], sv[r], bv[r]) : acc[r] + bv[r];
     if (a.act) x = (sizeof(T) == 4) ? silu_exact(x) : silu_fast(x);
     v[r] = x;
   }
@@ -164,11 +191,16 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] += __int_as_float(res[k]);
-    } else {
+    } else if constexpr (sizeof(T) == 2) {
       const v2i_t r2 = {res[0], res[1]};
       const f16x4 h = *reinterpret_cast<const f16x4*>(&r2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] += (float)h[k];
+    } else {
+      float rr[4];
+      unpack_fp8x4((uint32_t)res[0], rr);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaf(rr[k], a.res_scale, v[k]);
     }
   }
   constexpr int OS = OUTF32 ? 4 : (int)sizeof(T);
@@ -176,10 +208,20 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_
   if constexpr (OS == 4) {
     v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
     __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
-  } else {
+  } else if constexpr (OS == 2) {
     f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
     __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
+  } else {
+    const float q = a.out_inv_scale;
+    __builtin_amdgcn_raw_buffer_store_b32((int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), rdst, so, 0, 0);
   }
+}
+
+template <typename T, bool OUTF32>
+__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_buffer_rsrc_t& rdst, int m, int n,
+                                              const f32x4& acc, const float (&bv)[4], const v4ie_t& res) {
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  epilogue_fast<T, OUTF32>(a, rdst, m, n, acc, bv, res, one);
 }
 
 }  // namespace miyolo

@@ -286,6 +286,21 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   auto compute = [&](int slot) {
     const unsigned char* xs = smem + slot * STAGE;
     const unsigned char* ws = xs + BM * ROW_BYTES;
+    if constexpr (is_fp8<T>::value) {                  // one K = 128 MFMA per (channel tile, pixel tile): chunks q and q + 4
+      uint4 af[TC][2], bf[TPW][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) af[i][kk] = *reinterpret_cast<const uint4*>(ws + lds_off((wc * TC + i) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) bf[j][kk] = *reinterpret_cast<const uint4*>(xs + lds_off((wp * TPW + j) * 16 + frow, kk * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) mma_fp8(af[i][0], af[i][1], bf[j][0], bf[j][1], acc[i][j]);
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 af[TC], bf[TPW];
@@ -336,6 +351,27 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     constexpr int NM = 2 * TC * TPW;                 // MFMAs of the step
     const unsigned char* xs = smem + slot * STAGE;
     const unsigned char* ws = xs + BM * ROW_BYTES;
+    if constexpr (is_fp8<T>::value) {                  // K = 128 MFMAs (TC * TPW of them), the stage's DMAs spread between them
+      uint4 af[TC][2], bf[TPW][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) af[i][kk] = *reinterpret_cast<const uint4*>(ws + lds_off((wc * TC + i) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) bf[j][kk] = *reinterpret_cast<const uint4*>(xs + lds_off((wp * TPW + j) * 16 + frow, kk * 4 + fq));
+      }
+      constexpr int NM8 = TC * TPW;
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          mma_fp8(af[i][0], af[i][1], bf[j][0], bf[j][1], acc[i][j]);
+          const int q = i * TPW + j;
+#pragma unroll
+          for (int d = 0; d < NI; ++d)
+            if (q == (d * NM8) / NI) { if (MIYOLO_DMAP_ALWAYS_ISSUE || do_issue) issue_one(d); }
+        }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 af[TC], bf[TPW];
@@ -355,6 +391,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
           for (int d = 0; d < NI; ++d)
             if (q == (d * NM) / NI) { if (MIYOLO_DMAP_ALWAYS_ISSUE || do_issue) issue_one(d); }
         }
+    }
     }
     if (MIYOLO_DMAP_ALWAYS_ISSUE && !do_issue) d_slot = (d_slot == NST - 1) ? 0 : d_slot + 1;
     if (do_issue) {
@@ -488,6 +525,16 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+          float sv[4] = {1.f, 1.f, 1.f, 1.f};
+          if constexpr (is_fp8<T>::value) {        // per-output-channel dequantisation scale, same scalar-load route
+            const float* qp = sgpr_ptr(a.qscale + nt);
+            asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
+                         "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(qp));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              sv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
+          }
           v4ie_t rv[TPW];
           if (a.res) {                       // wave-uniform: all residual loads of this channel tile in flight together
 #pragma unroll
@@ -499,7 +546,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
             const int m = m0 + (wp * TPW + j) * 16 + frow;
-            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, m, n, acc[i][j], bv, rv[j]);
+            if (!ABL(8)) epilogue_fast<T, OUTF32>(a, rdst, m, n, acc[i][j], bv, rv[j], sv);
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
@@ -515,7 +562,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       } else if (a.vec_ok) {
         if (a.out_f32) run_epilogue(std::true_type{}); else run_epilogue(std::false_type{});
         v_stores += (ABL(8) ? 0 : NP);          // one vector store per 16x16 piece (its residual loads have been consumed)
-      } else {                                   // odd channel counts (e.g. nc = 13): scalar path
+      } else if constexpr (!is_fp8<T>::value) {      // odd channel counts (e.g. nc = 13): scalar path (fp8 requires vec_ok)
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
           const int n = n0 + (wc * TC + i) * 16 + fq * 4;

@@ -56,6 +56,19 @@ template <> struct Mma<half_t> {
   }
 };
 
+// fp8: ONE block-scaled MFMA covers a whole 128-byte row (K = 128) with unit block scales (e8m0 127 = 2^0).  A lane's
+// 32 bytes are chunks q and q+4 of its row (q = lane>>4) for BOTH operands - any assignment of the row's bytes to MFMA
+// k indices works as long as A and B use the same one - which keeps the f16 path's conflict-free ds_read_b128 pattern.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_fp8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, f32x4& c) {
+  const v8i_t av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+  const v8i_t bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+template <> struct Mma<fp8_t> {     // per-chunk form is not used for fp8 (see mma_fp8); declared so that shared code compiles
+  __device__ static __forceinline__ void run(const uint4&, const uint4&, f32x4&) {}
+};
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 

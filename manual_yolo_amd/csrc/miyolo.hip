@@ -39,7 +39,7 @@ using namespace miyolo;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;     // last error of a call without a handle (create, letterbox, crop_resize), per thread
 
 struct Plan {
   int B = 0, H = 0, W = 0;            // chunk batch and frame size the offsets are valid for
@@ -74,6 +74,8 @@ struct miyolo_engine {
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
   int dbg_op = -1;          // op index whose stamps are wanted
+  uint32_t cls_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // `classes=` filter of the NMS prefilter (miyolo_set_classes)
+  int use_cls_mask = 0;
   int profile = 0;          // 1: bracket every op launch with hipEvents (bench/roofline only)
   struct ProfRec { int op, cfg; hipEvent_t e0, e1; };
   std::vector<ProfRec> prof;
@@ -498,6 +500,8 @@ int run_nms(miyolo_engine* h, const Plan& p, const float* y, int Bc, int A, floa
   a.count = reinterpret_cast<int32_t*>(w + p.count_off);
   a.cls_idx = reinterpret_cast<int32_t*>(w + p.cls_off);
   a.out_dets = out_dets; a.out_counts = out_counts; a.out_anchor = out_anchor;
+  for (int i = 0; i < 8; ++i) a.cls_mask[i] = h->cls_mask[i];
+  a.use_mask = h->use_cls_mask;
   HIP_TRY(h, hipMemsetAsync(a.count, 0, (size_t)Bc * 4, s));
   hipLaunchKernelGGL(nms_prefilter_kernel, dim3((A + 255) / 256, Bc), dim3(256), 0, s, a);
   hipLaunchKernelGGL(nms_sort_greedy_kernel, dim3(Bc), dim3(kNmsThreads), (size_t)nms_lds_bytes(max_det), s, a);
@@ -578,7 +582,27 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   h->bufs.assign(bufs, bufs + desc->n_bufs);
   h->ops.assign(ops, ops + desc->n_ops);
   h->weights.assign(weights, weights + desc->n_weights);
+  for (const miyolo_buf& b : h->bufs)
+    if (b.down < 1 || b.channels < 1) { delete h; return fail(nullptr, MIYOLO_ERR_ARG, "buffer with channels %d / down %d", b.channels, b.down); }
   for (const miyolo_op& op : h->ops) {
+    auto bad_view = [&](const miyolo_view& v, bool optional) {
+      if (v.buf < 0) return !optional;
+      return v.buf >= desc->n_bufs || v.ch_off < 0 || v.ch_cnt < 1 || v.ch_off + v.ch_cnt > h->bufs[v.buf].channels;
+    };
+    bool bad = false;
+    if (op.kind == MIYOLO_OP_CONV) {
+      bad = op.n_src < 1 || op.n_src > 2 || bad_view(op.dst, false) || bad_view(op.res, true);
+      for (int i = 0; i < op.n_src && !bad; ++i) bad = bad_view(op.src[i], false);
+    } else if (op.kind == MIYOLO_OP_STEM) {
+      bad = bad_view(op.dst, false);
+    } else if (op.kind == MIYOLO_OP_MAXPOOL5) {
+      bad = bad_view(op.src[0], false) || bad_view(op.dst, false);
+    } else if (op.kind == MIYOLO_OP_DECODE) {
+      for (int i = 0; i < 3 && !bad; ++i) bad = bad_view(op.src[i], false) || op.level_stride[i] < 1;
+    } else if (op.kind == MIYOLO_OP_CLS_HEAD) {
+      bad = bad_view(op.src[0], false);
+    }
+    if (bad) { delete h; return fail(nullptr, MIYOLO_ERR_ARG, "op %d: view outside its buffer, or n_src out of range", (int)(&op - h->ops.data())); }
     const bool needs_w = op.kind == MIYOLO_OP_STEM || op.kind == MIYOLO_OP_CONV || op.kind == MIYOLO_OP_CLS_HEAD;
     if (needs_w && (op.weight < 0 || op.weight >= desc->n_weights || op.bias < 0 || op.bias >= desc->n_weights ||
                     !h->weights[op.weight] || !h->weights[op.bias])) {
@@ -628,7 +652,12 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   return 0;
 }
 
-void miyolo_destroy(miyolo_handle h) { if (h) drop_graphs(h); delete h; }
+void miyolo_destroy(miyolo_handle h) {
+  if (!h) return;
+  drop_graphs(h);
+  if (h->dbg) (void)hipFree(h->dbg);
+  delete h;
+}
 
 const char* miyolo_last_error(miyolo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -659,6 +688,22 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
     return 0;
   }
   return fail(h, MIYOLO_ERR_ARG, "unknown option %s", key);
+}
+
+int miyolo_set_classes(miyolo_handle h, const int32_t* classes, int n) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 0) return fail(h, MIYOLO_ERR_ARG, "not a detection model");
+  drop_graphs(h);
+  if (n <= 0 || !classes) { h->use_cls_mask = 0; return 0; }
+  if (h->desc.nc > 256) return fail(h, MIYOLO_ERR_UNSUPPORTED, "classes= filter supports at most 256 classes (model has %d)", h->desc.nc);
+  uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    if (classes[i] < 0 || classes[i] >= h->desc.nc) continue;      // a class the model does not have never matches, as upstream
+    m[classes[i] >> 5] |= 1u << (classes[i] & 31);
+  }
+  for (int i = 0; i < 8; ++i) h->cls_mask[i] = m[i];
+  h->use_cls_mask = 1;
+  return 0;
 }
 
 size_t miyolo_workspace_bytes(miyolo_handle h, int B, int H, int W) {
@@ -925,11 +970,9 @@ int miyolo_crop_resize(const void* frame, int H, int W, const int32_t* boxes, in
   a.tmp_rows = max_short + 2 * ((max_short + size - 1) / size) + 8;      // rows the vertical pass of S outputs can touch
   const size_t lds = crop_resize_lds_bytes(size, a.tmp_rows);
   if (lds > 160 * 1024) return fail(nullptr, MIYOLO_ERR_UNSUPPORTED, "crop_resize: %zu bytes of LDS needed", lds);
-  static bool attr_set = false;
-  if (!attr_set) {
+  {   // the attribute is per device; setting it is idempotent and cheap next to the launch, so no cached flag (no global state)
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crop_resize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "crop_resize attribute: %s", hipGetErrorString(e));
-    attr_set = true;
   }
   hipLaunchKernelGGL(crop_resize_kernel, dim3(n), dim3(256), lds, static_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();

@@ -43,6 +43,8 @@ struct NmsArgs {
   float* out_dets;                // [B, max_det, 6]
   int32_t* out_counts;            // [B]
   int32_t* out_anchor;            // [B, max_det] or null
+  uint32_t cls_mask[8];           // `classes=` filter: bit c set = class c passes (all ones: no filter); nc <= 256 when used
+  int32_t use_mask;
 };
 
 __global__ __launch_bounds__(256) void nms_prefilter_kernel(const NmsArgs a) {
@@ -55,6 +57,9 @@ __global__ __launch_bounds__(256) void nms_prefilter_kernel(const NmsArgs a) {
     const float s = yb[(long)c * a.A];
     if (s > best) { best = s; j = c; }
   }
+  // [3P] non_max_suppression: `x = x[(x[:, 5:6] == classes).any(1)]` - the best class must be a wanted one, BEFORE
+  // the sort / max_nms / NMS / max_det steps (oracle/post_ref.py:130-132)
+  if (a.use_mask && !((a.cls_mask[j >> 5] >> (j & 31)) & 1u)) return;
   if (best > a.conf) {
     const int slot = atomicAdd(a.count + b, 1);
     a.keys[(long)b * a.P + slot] =

@@ -59,6 +59,7 @@ SYMBOLS = {
     "miyolo_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "miyolo_chunk": (_i, [_vp, _i, _i, _i]),
     "miyolo_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "miyolo_set_classes": (_i, [_vp, _vp, _i]),
     "miyolo_detect": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "miyolo_head_raw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "miyolo_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -182,6 +183,12 @@ class Engine:
             self._graph = bool(value)
             self._gstream = torch.cuda.Stream(self.device) if value else None
             self._gout = {}
+
+    def set_classes(self, classes=None):
+        """`classes=` filter applied on the device BEFORE NMS (None / empty: no filter)."""
+        cl = [int(c) for c in classes] if classes is not None else []
+        arr = (C.c_int32 * max(len(cl), 1))(*cl)
+        self._check(self.lib.miyolo_set_classes(self.h, arr if cl else None, len(cl)), "miyolo_set_classes")
 
     def _graph_call(self, fn):
         """Run fn() on the graph side stream, ordered after / before the caller's current stream."""

@@ -107,6 +107,7 @@ class YOLO:
                                  device=eng.device)
             torch.cuda.synchronize(eng.device)
             t1 = time.perf_counter()
+            eng.set_classes(classes)          # filter on the device, before NMS, as [3P] non_max_suppression(classes=...)
             dets, counts, anchor = eng.detect(x, conf, iou, agnostic_nms, max_det, scale)
             torch.cuda.synchronize(eng.device)
             t2 = time.perf_counter()
@@ -116,9 +117,6 @@ class YOLO:
                 n = counts_c[i]
                 d = dets_c[i, :n].clone()
                 a = anchor_c[i, :n].clone()
-                if classes is not None:
-                    keep = torch.isin(d[:, 5], torch.tensor(list(classes), dtype=torch.float32))
-                    d, a = d[keep], a[keep]
                 out.append(Results(f, f"image{i}.jpg", self.names, boxes=d, anchor_idx=a))
             t3 = time.perf_counter()
         else:

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from manual_yolo_amd.dist import all_gather_detections, shard_bounds, unpad
+from manual_yolo_amd.dist import DetectionGather, all_gather_detections, shard_bounds, unpad
 
 
 def _free_port():
@@ -27,7 +27,16 @@ def _worker(rank, world, port, n_total, q):
         counts[i] = f % 4
         dets[i, : f % 4, 0] = float(f)
     gd, gc = all_gather_detections(dets, counts)
-    q.put((rank, gd.clone(), gc.clone()))
+    # the fused one-message form: the "engine" writes into the payload views, two batches through the two slots
+    g = DetectionGather(bl, 5, "cpu", depth=2)
+    fused = []
+    for step in range(3):
+        od, oc, _ = g.out_buffers(step)
+        od.copy_(dets + step); oc.copy_(counts)
+        g.launch(step)
+        fd, fc = g.wait(step)
+        fused.append((fd.clone(), fc.clone()))
+    q.put((rank, gd.clone(), gc.clone(), fused))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +63,11 @@ def test_all_gather_detections_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     bl = 4
-    for rank, gd, gc in got:
+    for rank, gd, gc, fused in got:
+        for step, (fd, fc) in enumerate(fused):            # one-message gather == two-collective gather
+            assert torch.equal(fc, gc) and fd.shape == gd.shape
+            for r in range(world):
+                assert torch.equal(fd[r * bl:(r + 1) * bl], gd[r * bl:(r + 1) * bl] + step)
         assert gd.shape == (world * bl, 5, 6) and gc.shape == (world * bl,)
         frames = unpad(gd, gc)
         # rank r's shard sits at rows [r*bl, r*bl + shard_len)
@@ -64,3 +77,12 @@ def test_all_gather_detections_world2():
                 rows = frames[r * bl + i]
                 assert rows.shape[0] == f % 4 and bool((rows[:, 0] == f).all())
     assert torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2])
+
+
+def test_detection_gather_world1_is_identity():
+    g = DetectionGather(3, 4, "cpu")
+    d, c, _ = g.out_buffers(0)
+    d.fill_(2.0); c.copy_(torch.tensor([1, 0, 4], dtype=torch.int32))
+    g.launch(0)
+    gd, gc = g.wait(0)
+    assert gd.shape == (3, 4, 6) and gc.tolist() == [1, 0, 4] and bool((gd == 2.0).all())

@@ -50,6 +50,20 @@ def test_fp16_logits_close(engines, rank_valid):
     assert np.array_equal(probs.argmax(1).cpu().numpy(), rank_valid["probs_best"].argmax(1))
 
 
+def test_fp16_batch_256_config2(engines, rank_valid):
+    """BASELINE config 2 as stated: yolov8n-cls, 64x64, batch 256, fp16 - every row against the golden fp32 logits at the
+    documented fp16 bar (|dlogit| < 0.15, same arg-max), and rows repeated across the batch bit-identical."""
+    pre = rank_valid["pre_u8"]
+    idx = np.arange(256) % len(pre)
+    x = torch.from_numpy(pre[idx]).cuda()
+    logits, probs = engines["best", "f16"].classify(x)
+    lg = logits.cpu().numpy()
+    assert np.abs(lg - rank_valid["logits_best"][idx]).max() < 0.15
+    assert np.array_equal(probs.argmax(1).cpu().numpy(), rank_valid["probs_best"].argmax(1)[idx])
+    assert np.array_equal(lg[:67], lg[67:134]) and np.array_equal(lg[:55], lg[201:256])
+    assert int((probs[:67].argmax(1).cpu().numpy() == rank_valid["labels"]).sum()) == 63
+
+
 @pytest.mark.parametrize("B", [1, 3, 256])
 def test_batch_sizes_and_determinism(engines, rank_valid, B):
     """Config 1 (B=1) and config 2 (B=256): every row equals the row computed in another batch."""

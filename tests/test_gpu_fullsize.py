@@ -91,5 +91,7 @@ def test_fullsize_kernel_generations_agree_bit_exactly_in_f32(model):
     yd = eng.head_raw(frames).cpu()
     assert torch.equal(ys[3], ys[1]), "conv_impl 1 differs from the ring kernel at full size"
     assert torch.isfinite(ys[3]).all()
-    assert (yd[:, 4:] - ys[3][:, 4:]).abs().max() < 1e-4, "scores: halo-slab kernel vs ring kernel"
-    assert (yd[:, :4] - ys[3][:, :4]).abs().max() < 2e-2, "boxes (px): halo-slab kernel vs ring kernel"
+    # 'blocks' frames are the saturated stress input on which the CPU fp32 path itself sits 1.8e-4 / 0.05 px from an fp64
+    # evaluation (test_gpu_detect.py): two fp32 summation orders may differ by a few times that
+    assert (yd[:, 4:] - ys[3][:, 4:]).abs().max() < 1e-3, "scores: halo-slab kernel vs ring kernel"
+    assert (yd[:, :4] - ys[3][:, :4]).abs().max() < 0.2, "boxes (px): halo-slab kernel vs ring kernel"
