@@ -426,7 +426,8 @@ def main():
         fl_step, by_step = eng.work(B, H, W)
         t_min_ms, mfrac = model_roofline(eng, B, H, W, args.dtype, ms_per_step)
         line = {
-            "metric": "frames/sec whole-node, yolov8m@640 batch=64; mAP delta vs CPU ref" if task == "detect"
+            "metric": ("frames/sec whole-node, yolov8m@640 batch=64; mAP delta vs CPU ref" if (H, B, args.scale) == (640, 64, "m")
+                       else f"frames/sec whole-node, yolov8{args.scale}@{H} batch={B}; mAP delta vs CPU ref") if task == "detect"
                       else "images/sec, yolov8n-cls rank classifier 64x64",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

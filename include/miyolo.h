@@ -50,7 +50,7 @@ typedef enum {
   MIYOLO_ERR_NO_DEVICE = -6    /* no gfx950 device visible */
 } miyolo_status;
 
-typedef enum { MIYOLO_F32 = 0, MIYOLO_F16 = 1 } miyolo_dtype;
+typedef enum { MIYOLO_F32 = 0, MIYOLO_F16 = 1, MIYOLO_F8 = 2 /* e4m3 (OCP) activations + weights, fp32 accumulate: config 5 */ } miyolo_dtype;
 
 typedef enum {
   MIYOLO_OP_STEM = 0,     /* conv3x3 s2 p1 on the uint8 3-channel input, /255 folded in, +bias, SiLU */
@@ -86,7 +86,15 @@ typedef struct {
   miyolo_view res;       /* CONV: residual added AFTER the activation (Bottleneck.add) or buf=-1 */
   int32_t weight, bias;  /* indices into the weight pointer table (CONV/STEM/CLS_HEAD) */
   int32_t level_stride[3]; /* DECODE: stride of each level (8,16,32) */
-  int32_t reserved[5];
+  /* MIYOLO_F8 only (ignored otherwise).  Quantisation is static, chosen by the host (manual_yolo_amd/quant.py):
+   * activation buffers hold e4m3 values q = x / s with one scale s per producing op; conv weights are e4m3 with one
+   * scale per output channel, the input scales folded in per input channel before quantising.  A conv computes
+   *   x[n] = acc[n] * qscale[n] + bias[n];  y = act(x) (+ res * res_scale);  stored = fp8(y * out_inv_scale)
+   * (fp32 raw head maps store y).  qscale / bias_init index the weight table: float [cout] padded like the bias;
+   * bias_init[n] = bias[n] / qscale[n] (accumulators of the halo-slab kernel start there). */
+  int32_t qscale, bias_init;
+  float out_inv_scale, res_scale;
+  int32_t reserved[1];
 } miyolo_op;
 
 typedef struct {
@@ -107,7 +115,7 @@ int miyolo_abi_version(void);
 /* Conv weight rows are [cout][kpad]: K = (ky,kx,cin) flattened (concat segments in order),
  * zero padded at the END to a multiple of this many elements (one staging step of the conv
  * kernel, 128 B): 32 for F32, 64 for F16.  Every source view must hold a multiple of
- * 16 B worth of channels (4 for F32, 8 for F16). */
+ * 16 B worth of channels (4 for F32, 8 for F16, 16 for F8; F8 rows are padded to 128 elements). */
 int miyolo_k_align(int dtype);
 
 /* Replaces: YOLO(path) model construction + AutoBackend(fuse=True) (detect.py:20-21).

@@ -99,10 +99,10 @@ struct ConvArgs {
   int32_t ablate;                   // timing experiments only (results wrong): 1 no tile DMA in the loop, 2 no MFMA, 4 no LDS reads
   int32_t exact;                    // 1: accurate expf in SiLU (fp32 parity mode)
   // fp8 path: conv value = acc * qscale[n] (per-output-channel weight scale x the folded input scales) + bias[n];
-  // the stored activation is value(after SiLU, + res * res_scale) * out_inv_scale, rounded to e4m3.  `bias` points at
-  // bias[n] / qscale[n] for kernels that start their accumulators at it (conv_h2.h); bias_raw at the bias itself.
+  // the stored activation is value(after SiLU, + res * res_scale) * out_inv_scale, rounded to e4m3.  bias_init =
+  // bias[n] / qscale[n], for kernels that start their accumulators at the bias (conv_h2.h).
   const float* qscale;
-  const float* bias_raw;
+  const float* bias_init;
   float out_inv_scale, res_scale;
 };
 
@@ -172,7 +172,7 @@ __device__ __forceinline__ v4ie_t epilogue_res_load(const ConvArgs& a, const __a
     const v2i_t r = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
     return (v4ie_t){r[0], r[1], 0, 0};
   } else {
-    return (v4ie_t){__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0), 0, 0, 0};
+    return (v4ie_t){(int)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0), 0, 0, 0};
   }
 }
 

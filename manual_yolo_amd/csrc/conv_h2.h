@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   const int ldB = a.src[0].ld * ES;
   const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.dst), 0, a.res ? a.res_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, g.bias_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(is_fp8<T>::value ? a.bias_init : a.bias), 0, g.bias_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rqs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(is_fp8<T>::value ? a.qscale : a.bias), 0, g.bias_bytes, 0x00020000);
 
   struct Tile { int bimg, y0, x0, n0; };
   auto tile_coords = [&](int L) -> Tile {
@@ -199,6 +200,27 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
     constexpr int dx = decltype(dx_tag)::value;
     const unsigned char* ws = smem + SLAB + slot * WSLOT;
     const unsigned char* xs = smem + dyoff;              // dy * HP * 128: the tap's row offset into the slab
+    if constexpr (is_fp8<T>::value) {                  // one K = 128 MFMA per tile pair: chunks q and q + 4 of the row
+      uint4 bf[TPW][2];                                // the pixel fragments stay, the weight fragments stream (register budget)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) bf[j][kk] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6)));
+      uint4 a0 = *reinterpret_cast<const uint4*>(ws + aaddr), a1 = *reinterpret_cast<const uint4*>(ws + (aaddr ^ 64u));
+#pragma unroll
+      for (int i = 0; i < TC; ++i) {                   // one channel tile ahead, pinned: the scheduler would otherwise hoist all
+        uint4 n0 = a0, n1 = a1;                        // twelve reads and spill
+        if (i + 1 < TC) {
+          n0 = *reinterpret_cast<const uint4*>(ws + aaddr + (i + 1) * 16 * ROW_BYTES);
+          n1 = *reinterpret_cast<const uint4*>(ws + (aaddr ^ 64u) + (i + 1) * 16 * ROW_BYTES);
+        }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) mma_fp8(a0, a1, bf[j][0], bf[j][1], acc[i][j]);
+        a0 = n0; a1 = n1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk == 1 && !full) break;                     // tail chunk with <= half a row of channels (wave-uniform)
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 
   auto act = [&](float x) -> float {
     if (!a.act) return x;
-    if constexpr (ES == 4) return silu_exact(x); else return silu_fast(x);
+    if constexpr (ES == 4) return silu_exact(x); else return silu_fast(x);     // f16 / fp8: v_exp + v_rcp
   };
 
 #if MIYOLO_ABLATE
@@ -295,6 +317,21 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       const int n = cur.n0 + 32 * ip + 8 * fq;
       const bool nok = n < a.cout;
       v4ie_t r0[TPW], r1[TPW];
+      float qm[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if constexpr (ES == 1) {             // fp8: per-channel dequantisation scale of this lane's 8 channels; residual bytes
+        const v4ie_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rqs, (uint32_t)(n * 4), 0, 0);
+        const v4ie_t q1 = __builtin_amdgcn_raw_buffer_load_b128(rqs, (uint32_t)(n * 4 + 16), 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { qm[r] = __int_as_float(q0[r]); qm[4 + r] = __int_as_float(q1[r]); }
+        if (a.res) {
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)(mpix[j] * a.res_ld + a.res_choff + n) : kOob;
+            const v2i_t rr = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
+            r0[j] = (v4ie_t){rr[0], rr[1], 0, 0};
+          }
+        }
+      }
       if constexpr (ES == 2) {
         if (a.res) {                     // f16: the four residual loads of a channel pair in flight together
 #pragma unroll
@@ -315,9 +352,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
         }
         float v[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] = act(acc[2 * ip][j][r]); v[4 + r] = act(acc[2 * ip + 1][j][r]); }
+        for (int r = 0; r < 4; ++r) { v[r] = act(acc[2 * ip][j][r] * qm[r]); v[4 + r] = act(acc[2 * ip + 1][j][r] * qm[4 + r]); }
         if (a.res) {
-          if constexpr (ES == 4) {
+          if constexpr (ES == 1) {
+            float ra[4], rb[4];
+            unpack_fp8x4((uint32_t)r0[j][0], ra); unpack_fp8x4((uint32_t)r0[j][1], rb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = fmaf(ra[r], a.res_scale, v[r]); v[4 + r] = fmaf(rb[r], a.res_scale, v[4 + r]); }
+          } else if constexpr (ES == 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] += __int_as_float(r0[j][r]); v[4 + r] += __int_as_float(r1[j][r]); }
           } else {
@@ -327,7 +369,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
           }
         }
         const uint32_t so = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
-        if constexpr (ES == 4) {
+        if constexpr (ES == 1) {
+          const float q = a.out_inv_scale;
+          const v2i_t o = {(int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), (int)pack_fp8x4(v[4] * q, v[5] * q, v[6] * q, v[7] * q)};
+          __builtin_amdgcn_raw_buffer_store_b64(o, rdst, so, 0, 0);
+        } else if constexpr (ES == 4) {
           const v4ie_t o0 = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
           const v4ie_t o1 = {__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
           __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, 0);
@@ -342,15 +388,26 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       constexpr int i = TC - 1;
       const int n = cur.n0 + 16 * i + 4 * fq;
       const bool nok = n < a.cout;
+      float qm[4] = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (ES == 1) {
+        const v4ie_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rqs, (uint32_t)(n * 4), 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qm[r] = __int_as_float(q0[r]);
+      }
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act(acc[i][j][r]);
+        for (int r = 0; r < 4; ++r) v[r] = act(acc[i][j][r] * qm[r]);
         const bool ok = nok && mpix[j] >= 0;
         if (a.res) {
           const uint32_t ro = ok ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
-          if constexpr (ES == 4) {
+          if constexpr (ES == 1) {
+            float ra[4];
+            unpack_fp8x4((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0), ra);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(ra[r], a.res_scale, v[r]);
+          } else if constexpr (ES == 4) {
             const v4ie_t rr = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += __int_as_float(rr[r]);
@@ -362,7 +419,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
           }
         }
         const uint32_t so = ok ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
-        if constexpr (ES == 4) {
+        if constexpr (ES == 1) {
+          const float q = a.out_inv_scale;
+          __builtin_amdgcn_raw_buffer_store_b32((int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), rdst, so, 0, 0);
+        } else if constexpr (ES == 4) {
           const v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
           __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
         } else {
@@ -395,6 +455,7 @@ template <int TC> constexpr size_t h2_wring_bytes() { return (size_t)2 * ((TC * 
 inline int h2_pick_tc(int cout, int elem = 2) {
   // channel tile: 96 where it divides or the tail is small, else 64 / 48
   if (elem == 4) return (cout % 48 == 0 || cout <= 48) ? 3 : (cout % 64 == 0 || cout <= 64) ? 4 : 3;   // fp32 (parity mode): 96-channel tiles spill
+  if (elem == 1) return (cout % 64 == 0 || (cout > 48 && cout <= 64)) ? 4 : 3;   // fp8: 32-byte fragments, 96-channel tiles spill too
   if (cout <= 48) return 3;
   if (cout <= 64) return 4;
   if (cout % 96 == 0) return 6;
@@ -481,7 +542,10 @@ inline hipError_t launch_conv_h2(const ConvArgs& a, hipStream_t s, int ncu, int 
   switch (tc) {
     case 3: launch_h2_geo<T, 3>(a, g, geo, lds, s); break;
     case 4: launch_h2_geo<T, 4>(a, g, geo, lds, s); break;
-    default: launch_h2_geo<T, 6>(a, g, geo, lds, s); break;
+    default:
+      if constexpr (!is_fp8<T>::value) launch_h2_geo<T, 6>(a, g, geo, lds, s);
+      else return hipErrorInvalidValue;
+      break;
   }
   return hipGetLastError();
 }
@@ -492,8 +556,8 @@ inline hipError_t set_h2_attrs() {
 #define MIYOLO_H2_ATTR(TC, GEO)                                                                         \
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<T, TC, GEO>),               \
                                hipFuncAttributeMaxDynamicSharedMemorySize, kH2LdsMax)) != hipSuccess) return e;
-  MIYOLO_H2_ATTR(3, 0) MIYOLO_H2_ATTR(4, 0) MIYOLO_H2_ATTR(6, 0) MIYOLO_H2_ATTR(3, 1) MIYOLO_H2_ATTR(4, 1) MIYOLO_H2_ATTR(6, 1)
-  MIYOLO_H2_ATTR(3, 2) MIYOLO_H2_ATTR(4, 2) MIYOLO_H2_ATTR(6, 2)
+  MIYOLO_H2_ATTR(3, 0) MIYOLO_H2_ATTR(4, 0) MIYOLO_H2_ATTR(3, 1) MIYOLO_H2_ATTR(4, 1) MIYOLO_H2_ATTR(3, 2) MIYOLO_H2_ATTR(4, 2)
+  if constexpr (!is_fp8<T>::value) { MIYOLO_H2_ATTR(6, 0) MIYOLO_H2_ATTR(6, 1) MIYOLO_H2_ATTR(6, 2) }
 #undef MIYOLO_H2_ATTR
   return hipSuccess;
 }

@@ -24,11 +24,13 @@ struct StemArgs {
   const float* bias;   // [cout]
   void* out;           // [B,H/2,W/2,cout] T
   int32_t B, H, W, Ho, Wo, cout, act, exact;
+  float out_inv_scale;  // OUT8: stored byte = fp8(value * out_inv_scale)
   uint32_t in_bytes;
   uint32_t mg_hw_mul, mg_hw_shift, mg_w_mul, mg_w_shift;   // host_magic(Ho*Wo), host_magic(Wo): no 64-bit divides per tile
 };
 
-template <typename T, int TCS>
+// OUT8: compute as T (= half), store fp8 e4m3 bytes (the fp8 engine's first activation buffer).
+template <typename T, int TCS, bool OUT8 = false>
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   constexpr int CE = DT<T>::CE;
   const int lane = threadIdx.x & 63, frow = lane & 15, q = lane >> 4;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     }
     if (vm) {
       T* op = reinterpret_cast<T*>(a.out) + m * a.cout + q * 4;
+      unsigned char* op8 = reinterpret_cast<unsigned char*>(a.out) + m * a.cout + q * 4;
 #pragma unroll
       for (int tc = 0; tc < TCS; ++tc) {
         float v[4];
@@ -108,7 +111,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
           if (a.act) y = a.exact ? silu_exact(y) : silu_fast(y);
           v[r] = y;
         }
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (OUT8) {
+          const float qs = a.out_inv_scale;
+          *reinterpret_cast<uint32_t*>(op8 + tc * 16) = pack_fp8x4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
+        } else if constexpr (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(op + tc * 16) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -156,6 +162,49 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const PoolArgs a) {
   }
   T* dp = reinterpret_cast<T*>(a.dst);
   *reinterpret_cast<vec_t*>(dp + (((long)b * a.H + h) * a.W + w) * a.dst_ld + a.dst_choff + cc * CE) = best;
+}
+
+// fp8: 16 channels per thread; e4m3 bytes are compared through their float values (the byte patterns are sign-magnitude,
+// not two's complement) and the winning BYTE is kept, so the result is exact; the slice keeps its producer's scale.
+template <>
+__global__ __launch_bounds__(256) void maxpool5_kernel<fp8_t>(const PoolArgs a) {
+  const int nch = a.ch / 16;
+  const long total = (long)a.B * a.H * a.W * nch;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cc = (int)(idx % nch);
+  long p = idx / nch;
+  const int w = (int)(p % a.W);
+  p /= a.W;
+  const int h = (int)(p % a.H), b = (int)(p / a.H);
+  const unsigned char* sp = reinterpret_cast<const unsigned char*>(a.src);
+  float best[16];
+  unsigned char bb[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { best[k] = -1e30f; bb[k] = 0; }
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int hh = h + dy;
+    if (hh < 0 || hh >= a.H) continue;
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int ww = w + dx;
+      if (ww < 0 || ww >= a.W) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(sp + (((long)b * a.H + hh) * a.W + ww) * a.src_ld + a.src_choff + cc * 16);
+      const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float f[4];
+        unpack_fp8x4(wv[q], f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (f[r] > best[q * 4 + r]) { best[q * 4 + r] = f[r]; bb[q * 4 + r] = (unsigned char)(wv[q] >> (8 * r)); }
+      }
+    }
+  }
+  uint32_t o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = (uint32_t)bb[q * 4] | ((uint32_t)bb[q * 4 + 1] << 8) | ((uint32_t)bb[q * 4 + 2] << 16) | ((uint32_t)bb[q * 4 + 3] << 24);
+  unsigned char* dp = reinterpret_cast<unsigned char*>(a.dst);
+  *reinterpret_cast<uint4*>(dp + (((long)b * a.H + h) * a.W + w) * a.dst_ld + a.dst_choff + cc * 16) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -293,6 +342,18 @@ template <typename T>
 __global__ void copy_from_f32_kernel(const float* src, T* dst, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = (T)src[i];
+}
+
+// fp8 buffers: the taps move the stored e4m3 values (UNSCALED: the host multiplies by the buffer's activation scale)
+template <>
+__global__ void copy_to_f32_kernel<fp8_t>(const fp8_t* src, float* dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = __builtin_amdgcn_cvt_f32_fp8((int)src[i].v, 0);
+}
+template <>
+__global__ void copy_from_f32_kernel<fp8_t>(const float* src, fp8_t* dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i].v = (unsigned char)(pack_fp8x4(src[i], 0.f, 0.f, 0.f) & 0xFFu);
 }
 
 }  // namespace miyolo

@@ -104,7 +104,7 @@ int fail(miyolo_engine* h, int code, const char* fmt, ...) {
 inline size_t elem_size(const miyolo_engine* h, const miyolo_buf& b) {
   if (b.dtype == -2) return 1;                       // uint8 input
   if (b.dtype == MIYOLO_F32) return 4;
-  return h->desc.dtype == MIYOLO_F16 ? 2 : 4;        // -1: activation dtype
+  return h->desc.dtype == MIYOLO_F16 ? 2 : h->desc.dtype == MIYOLO_F8 ? 1 : 4;        // -1: activation dtype
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -300,12 +300,23 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
         return fail(h, MIYOLO_ERR_UNSUPPORTED, "stem: cout=%d must be a multiple of 16 (<= 80) and own its buffer", op.cout);
       const long ntiles = ((long)Bc * a.Ho * a.Wo + 15) / 16;
       const unsigned grid = (unsigned)std::min<long>((ntiles + 3) / 4, 256 * 8);
+      a.out_inv_scale = op.out_inv_scale;
+      if constexpr (is_fp8<T>::value) {         // fp8 engine: the stem computes in f16 (f16 weights) and stores e4m3
+        switch (op.cout / 16) {
+          case 1: hipLaunchKernelGGL((stem_kernel<half_t, 1, true>), dim3(grid), dim3(256), 0, s, a); break;
+          case 2: hipLaunchKernelGGL((stem_kernel<half_t, 2, true>), dim3(grid), dim3(256), 0, s, a); break;
+          case 3: hipLaunchKernelGGL((stem_kernel<half_t, 3, true>), dim3(grid), dim3(256), 0, s, a); break;
+          case 4: hipLaunchKernelGGL((stem_kernel<half_t, 4, true>), dim3(grid), dim3(256), 0, s, a); break;
+          default: hipLaunchKernelGGL((stem_kernel<half_t, 5, true>), dim3(grid), dim3(256), 0, s, a); break;
+        }
+      } else {
       switch (op.cout / 16) {
         case 1: hipLaunchKernelGGL((stem_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((stem_kernel<T, 2>), dim3(grid), dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL((stem_kernel<T, 3>), dim3(grid), dim3(256), 0, s, a); break;
         case 4: hipLaunchKernelGGL((stem_kernel<T, 4>), dim3(grid), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((stem_kernel<T, 5>), dim3(grid), dim3(256), 0, s, a); break;
+      }
       }
       break;
     }
@@ -357,11 +368,24 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.vec_ok = (op.cout % 4 == 0) && (ob.channels % 4 == 0) && (op.dst.ch_off % 4 == 0) &&
                  (op.res.buf < 0 || (h->bufs[op.res.buf].channels % 4 == 0 && op.res.ch_off % 4 == 0));
       a.exact = (h->desc.dtype == MIYOLO_F32);
+      if constexpr (is_fp8<T>::value) {
+        if (op.qscale < 0 || op.qscale >= (int)h->weights.size() || op.bias_init < 0 || op.bias_init >= (int)h->weights.size() || !a.vec_ok)
+          return fail(h, MIYOLO_ERR_ARG, "fp8 conv needs qscale / bias_init weight entries and 4-channel aligned views");
+        a.qscale = static_cast<const float*>(h->weights[op.qscale]);
+        a.bias_init = static_cast<const float*>(h->weights[op.bias_init]);
+        a.out_inv_scale = op.out_inv_scale; a.res_scale = op.res_scale;
+      }
       a.ablate = h->ablate;
       a.dbg = (h->dbg && (&op - h->ops.data()) == h->dbg_op) ? h->dbg : nullptr;
       a.res_vec = a.res && (a.res_ld % 4 == 0) && (a.res_choff % 4 == 0) && (op.cout % 4 == 0);
       host_magic((uint32_t)(a.Hout * a.Wout), &a.mg_hw_mul, &a.mg_hw_shift);
       host_magic((uint32_t)a.Wout, &a.mg_w_mul, &a.mg_w_shift);
+      if constexpr (is_fp8<T>::value) {         // fp8: the halo-slab kernel where eligible, else the persistent ring kernel
+        if (h->conv_impl != 3 && h->conv_impl != 8) return fail(h, MIYOLO_ERR_UNSUPPORTED, "fp8 runs on conv_impl 3 / 8 only");
+        if ((h->conv_impl == 8 || (h->h2 && h->force_wc == 0)) && h2_eligible<T>(a, h->conv_impl == 8 ? 0.0 : 0.01 * h->h2_min_util))
+          HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
+        else HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      } else {
       if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
       else if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && t2d_eligible<T>(a))
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
@@ -376,6 +400,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
       else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
+      }
       break;
     }
     case MIYOLO_OP_MAXPOOL5: {
@@ -412,6 +437,8 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       break;
     }
     case MIYOLO_OP_CLS_HEAD: {
+      if constexpr (is_fp8<T>::value) return fail(h, MIYOLO_ERR_UNSUPPORTED, "classification is not built for fp8");
+      else {
       const miyolo_buf& sb = h->bufs[op.src[0].buf];
       ClsHeadArgs a;
       a.feat = buf_ptr(h, p, op.src[0].buf, in, ws);
@@ -421,6 +448,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       a.B = Bc; a.hw = (H / sb.down) * (W / sb.down); a.c = op.cin; a.nc = op.cout;
       if (op.src[0].ch_off != 0 || sb.channels != op.cin) return fail(h, MIYOLO_ERR_UNSUPPORTED, "cls head must read a whole buffer");
       hipLaunchKernelGGL(cls_head_kernel<T>, dim3(Bc), dim3(256), (size_t)(a.c + a.nc) * 4, s, a);
+      }
       break;
     }
     default:
@@ -437,11 +465,12 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   T2dGeom tg; size_t tlds;
   const bool t2d = (h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0)) && op.ksize == 3 && op.stride == 1 &&
                    op.n_src == 1 && !op.src[0].upsample &&
+                   h->desc.dtype != MIYOLO_F8 &&
                    t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
   const bool s1 = op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample && ob.dtype != MIYOLO_F32 && op.cout % 8 == 0;
   if (s1 && (h->conv_impl == 8 || (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && !t2d))) {
     H2Geom hg; size_t hl; int hgeo;
-    const int es = h->desc.dtype == MIYOLO_F16 ? 2 : 4, tc = h2_pick_tc(op.cout, es);
+    const int es = h->desc.dtype == MIYOLO_F16 ? 2 : h->desc.dtype == MIYOLO_F8 ? 1 : 4, tc = h2_pick_tc(op.cout, es);
     if (h2_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, es, 16 / es, tc, &hg, &hl, &hgeo) &&
         (h->conv_impl == 8 || h2_util(hg, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h2_min_util))
       return 8000 + 300 + 40 + tc;                          // conv_h2_kernel<T,TC>
@@ -477,7 +506,8 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
       HIP_TRY(h, hipEventCreate(&rec.e1));
       HIP_TRY(h, hipEventRecord(rec.e0, s));
     }
-    const int rc = (h->desc.dtype == MIYOLO_F16)
+    const int rc = (h->desc.dtype == MIYOLO_F8) ? run_op<fp8_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s)
+                   : (h->desc.dtype == MIYOLO_F16)
                        ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s)
                        : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s);
     if (rc) return rc;
@@ -560,13 +590,13 @@ extern "C" {
 
 int miyolo_abi_version(void) { return MIYOLO_ABI_VERSION; }
 
-int miyolo_k_align(int dtype) { return dtype == MIYOLO_F16 ? 64 : 32; }
+int miyolo_k_align(int dtype) { return dtype == MIYOLO_F8 ? 128 : dtype == MIYOLO_F16 ? 64 : 32; }
 
 int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_op* ops,
                   const void* const* weights, int device, miyolo_handle* out) {
   if (!desc || !bufs || !ops || !weights || !out) return fail(nullptr, MIYOLO_ERR_ARG, "null argument");
   if (desc->abi_version != MIYOLO_ABI_VERSION) return fail(nullptr, MIYOLO_ERR_ARG, "ABI version %d != %d", desc->abi_version, MIYOLO_ABI_VERSION);
-  if (desc->dtype != MIYOLO_F32 && desc->dtype != MIYOLO_F16) return fail(nullptr, MIYOLO_ERR_ARG, "bad dtype %d", desc->dtype);
+  if (desc->dtype != MIYOLO_F32 && desc->dtype != MIYOLO_F16 && desc->dtype != MIYOLO_F8) return fail(nullptr, MIYOLO_ERR_ARG, "bad dtype %d", desc->dtype);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MIYOLO_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(nullptr, MIYOLO_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
@@ -625,6 +655,9 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_dmap_attrs_ks<half_t, 3>();
   if (e == hipSuccess) e = set_h2_attrs<float>();
   if (e == hipSuccess) e = set_h2_attrs<half_t>();
+  if (e == hipSuccess) e = set_h2_attrs<fp8_t>();
+  if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 1>();
+  if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 3>();
   if (e == hipSuccess) e = set_t2d_attrs<float>();
   if (e == hipSuccess) e = set_t2d_attrs<half_t>();
 #if MIYOLO_EXPERIMENTS
@@ -842,6 +875,9 @@ int miyolo_read_buffer(miyolo_handle h, int buf, int B, int H, int W, float* out
   const unsigned g = (unsigned)((n + 255) / 256);
   if (elem_size(h, h->bufs[buf]) == 4) {
     HIP_TRY(h, hipMemcpyAsync(out, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  } else if (elem_size(h, h->bufs[buf]) == 1) {
+    hipLaunchKernelGGL(copy_to_f32_kernel<fp8_t>, dim3(g), dim3(256), 0, s, static_cast<const fp8_t*>(src), out, n);
+    HIP_TRY(h, hipGetLastError());
   } else {
     hipLaunchKernelGGL(copy_to_f32_kernel<half_t>, dim3(g), dim3(256), 0, s, static_cast<const half_t*>(src), out, n);
     HIP_TRY(h, hipGetLastError());
@@ -859,6 +895,9 @@ int miyolo_write_buffer(miyolo_handle h, int buf, int B, int H, int W, const flo
   const unsigned g = (unsigned)((n + 255) / 256);
   if (elem_size(h, h->bufs[buf]) == 4) {
     HIP_TRY(h, hipMemcpyAsync(dst, in, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  } else if (elem_size(h, h->bufs[buf]) == 1) {
+    hipLaunchKernelGGL(copy_from_f32_kernel<fp8_t>, dim3(g), dim3(256), 0, s, in, static_cast<fp8_t*>(dst), n);
+    HIP_TRY(h, hipGetLastError());
   } else {
     hipLaunchKernelGGL(copy_from_f32_kernel<half_t>, dim3(g), dim3(256), 0, s, in, static_cast<half_t*>(dst), n);
     HIP_TRY(h, hipGetLastError());
@@ -899,7 +938,7 @@ int miyolo_op_work(miyolo_handle h, int op_index, int B, int H, int W, double* f
   if (int rc = check_shape(h, B, H, W)) return rc;
   const miyolo_op& op = h->ops[op_index];
   double fl = 0, by = 0;
-  const double es = h->desc.dtype == MIYOLO_F16 ? 2 : 4;
+  const double es = h->desc.dtype == MIYOLO_F16 ? 2 : h->desc.dtype == MIYOLO_F8 ? 1 : 4;
   if (op.kind == MIYOLO_OP_CONV || op.kind == MIYOLO_OP_STEM) {
     const miyolo_buf& ob = h->bufs[op.dst.buf];
     const double mo = (double)B * (H / ob.down) * (W / ob.down);

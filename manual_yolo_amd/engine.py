@@ -19,7 +19,7 @@ from .weights import K_ALIGN, build_weight_tensors
 
 # MIYOLO_LIB: an alternative build of the same ABI (A/B timing of kernel variants on one box); still no CPU fallback
 _LIB_PATH = os.environ.get("MIYOLO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmiyolo.so")
-DT_CODE = {"f32": 0, "f16": 1}
+DT_CODE = {"f32": 0, "f16": 1, "f8": 2}
 
 
 class MiyoloError(RuntimeError):
@@ -39,7 +39,8 @@ class _Op(C.Structure):
                 ("cin", C.c_int32), ("cout", C.c_int32), ("n_src", C.c_int32),
                 ("src", _View * 3), ("dst", _View), ("res", _View),
                 ("weight", C.c_int32), ("bias", C.c_int32),
-                ("level_stride", C.c_int32 * 3), ("reserved", C.c_int32 * 5)]
+                ("level_stride", C.c_int32 * 3), ("qscale", C.c_int32), ("bias_init", C.c_int32),
+                ("out_inv_scale", C.c_float), ("res_scale", C.c_float), ("reserved", C.c_int32 * 1)]
 
 
 class _Desc(C.Structure):
@@ -127,7 +128,7 @@ class Engine:
     """One model on one GPU.  Not re-entrant (one call in flight), as the C ABI states."""
 
     def __init__(self, prog: Program, sd: Dict[str, torch.Tensor], bn_eps: float, dtype: str = "f16",
-                 device: Optional[int] = None, bgr_input: bool = True):
+                 device: Optional[int] = None, bgr_input: bool = True, quant=None):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise MiyoloError("no GPU visible: the MI355X path has no CPU fallback")
@@ -135,7 +136,26 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         self.prog, self.dtype = prog, dtype
         self.nc = prog.nc
-        cpu_w = build_weight_tensors(prog, sd, bn_eps, dtype, bgr_input)
+        self.quant = quant
+        self.f8_extra = {}
+        extra = {}
+        if dtype == "f8":
+            # the conv kernels switch K segments per 128-byte K step: the FIRST segment of a two-view 1x1 conv must be a
+            # multiple of 128 channels.  Where only the second one is (yolov8m: cat(up(576), 384), cat(192, 384)), swap the
+            # views - the weight columns are permuted to match in build_weight_tensors (op.swapped).
+            import copy
+            prog = copy.deepcopy(prog)
+            for op in prog.ops:
+                if op.kind == 1 and len(op.src) == 2 and op.src[0].ch_cnt % 128 and op.src[1].ch_cnt % 128 == 0:
+                    op.src = [op.src[1], op.src[0]]
+                    op.swapped = op.src[1].ch_cnt                 # channels of the ORIGINAL first segment
+            self.prog = prog
+            if quant is None:
+                raise MiyoloError("dtype f8 needs a quant.QuantSpec (engine_from_weights calibrates one)")
+            cpu_w, extra = build_weight_tensors(prog, sd, bn_eps, dtype, bgr_input, quant)
+            self.f8_extra = extra
+        else:
+            cpu_w = build_weight_tensors(prog, sd, bn_eps, dtype, bgr_input)
         self.weights = [w.to(self.device) for w in cpu_w]   # kept alive for the handle's lifetime
         bufs = (_Buf * len(prog.bufs))(*[_Buf(c, d, dt, 0) for (c, d, dt) in prog.bufs])
         ops = (_Op * len(prog.ops))()
@@ -149,6 +169,17 @@ class Engine:
             o.weight, o.bias = op.weight, op.bias
             for j in range(3):
                 o.level_stride[j] = op.level_stride[j]
+            o.qscale, o.bias_init, o.out_inv_scale, o.res_scale = -1, -1, 1.0, 1.0
+            if dtype == "f8":
+                if i in extra:
+                    o.qscale, o.bias_init = extra[i]
+                if i in quant.out_scale:
+                    o.out_inv_scale = 1.0 / quant.out_scale[i]
+                if op.res is not None:
+                    rs = quant.buf_scale[op.res.buf][op.res.ch_off:op.res.ch_off + op.res.ch_cnt]
+                    if float(rs.max()) != float(rs.min()):
+                        raise MiyoloError(f"{op.name}: residual slice spans several activation scales")
+                    o.res_scale = float(rs[0])
         desc = _Desc(1, 0 if prog.task == "detect" else 1, DT_CODE[dtype], prog.nc, 16, prog.max_stride,
                      len(prog.bufs), len(prog.ops), len(self.weights))
         wptrs = (C.c_void_p * len(self.weights))(*[w.data_ptr() for w in self.weights])
@@ -297,10 +328,14 @@ class Engine:
         out = torch.empty(self.buffer_shape(buf, B, H, W), dtype=torch.float32, device=self.device)
         self._check(self.lib.miyolo_read_buffer(self.h, buf, B, H, W, out.data_ptr(), ws.data_ptr(), self._stream()),
                     "miyolo_read_buffer")
+        if self.dtype == "f8" and buf in self.quant.buf_scale:       # stored e4m3 values -> real activations
+            out *= torch.from_numpy(self.quant.buf_scale[buf]).to(self.device)
         return out
 
     def write_buffer(self, buf: int, x: torch.Tensor, H: int, W: int):
         x = x.to(self.device, torch.float32).contiguous()
+        if self.dtype == "f8" and buf in self.quant.buf_scale:
+            x = (x / torch.from_numpy(self.quant.buf_scale[buf]).to(self.device)).contiguous()
         B = x.shape[0]
         assert tuple(x.shape) == self.buffer_shape(buf, B, H, W), (tuple(x.shape), self.buffer_shape(buf, B, H, W))
         ws = self.workspace(B, H, W)
@@ -339,6 +374,28 @@ class Engine:
 
 
 def engine_from_weights(sd: Dict[str, torch.Tensor], meta: dict, dtype: str = "f16", device: Optional[int] = None,
-                        bgr_input: bool = True) -> Engine:
+                        bgr_input: bool = True, calib_frames: Optional[torch.Tensor] = None, quant=None,
+                        gain_fix: bool = True) -> Engine:
+    """dtype "f8" (detect only): static e4m3 quantisation, calibrated on `calib_frames` (uint8 [N,H,W,3]; default: eight
+    seeded synthetic frames at the model's image size) through the f16 engine, followed by the per-op gain correction
+    of quant.gain_correction - see quant.py."""
     prog = build_program(meta["task"], meta["nc"], meta["scale"], meta.get("spec"), meta.get("nc_quirk", True))
-    return Engine(prog, sd, meta["bn_eps"], dtype, device, bgr_input)
+    if dtype != "f8":
+        return Engine(prog, sd, meta["bn_eps"], dtype, device, bgr_input, quant)
+    from .quant import calibrate, gain_correction
+    if meta["task"] != "detect":
+        raise MiyoloError("fp8 is built for the detect path only")
+    if calib_frames is None:
+        from .synth import synth_frames
+        sz = int(meta.get("imgsz", 640))
+        calib_frames = torch.from_numpy(np.concatenate([synth_frames(4, sz, sz, seed=101, kind="noise"),
+                                                        synth_frames(4, sz, sz, seed=102, kind="blocks")]))
+    eng16 = Engine(prog, sd, meta["bn_eps"], "f16", device, bgr_input) if (quant is None or gain_fix) else None
+    if quant is None:
+        quant = calibrate(prog, sd, meta["bn_eps"], calib_frames, device, bgr_input, eng16=eng16)
+    eng = Engine(prog, sd, meta["bn_eps"], "f8", device, bgr_input, quant)
+    if gain_fix:
+        n = max(1, min(4, calib_frames.shape[0], eng.chunk(4, calib_frames.shape[1], calib_frames.shape[2])))
+        eng.gains = gain_correction(eng, eng16, calib_frames[:n])
+    del eng16
+    return eng

@@ -13,8 +13,8 @@ import torch
 
 from .arch import Program, WeightRecipe
 
-K_ALIGN = {"f32": 32, "f16": 64}      # must equal miyolo_k_align(); checked in engine.py
-CHUNK_ELEMS = {"f32": 4, "f16": 8}
+K_ALIGN = {"f32": 32, "f16": 64, "f8": 128}      # must equal miyolo_k_align(); checked in engine.py
+CHUNK_ELEMS = {"f32": 4, "f16": 8, "f8": 16}
 TORCH_DTYPE = {"f32": torch.float32, "f16": torch.float16}
 
 
@@ -61,13 +61,23 @@ def pack_stem_weight(wf: torch.Tensor, bgr_input: bool, dtype: str) -> torch.Ten
     return out.to(TORCH_DTYPE[dtype]).contiguous()
 
 
+def _pad128(v: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(((v.numel() + 127) // 128 * 128,), dtype=torch.float32)    # padded: the persistent conv kernel
+    out[:v.numel()] = v                                                        # s_loads 16 at a time
+    return out
+
+
 def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float, dtype: str,
-                         bgr_input: bool = True) -> List[torch.Tensor]:
-    """One CPU tensor per ``prog.weights`` entry, ready for ``.to(device)``."""
+                         bgr_input: bool = True, quant=None):
+    """One CPU tensor per ``prog.weights`` entry, ready for ``.to(device)``.  dtype "f8" (``quant`` = quant.QuantSpec):
+    conv weights are e4m3 bytes with the input scales folded in, and the list gets two extra fp32 tensors per conv op
+    (qscale, bias_init = bias / qscale); returns ``(tensors, extra)`` with ``extra[op_index] = (qscale_idx, bias_init_idx)``."""
     out: List[torch.Tensor] = []
     folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
     ce = CHUNK_ELEMS[dtype]
-    for r in prog.weights:
+    op_of_weight = {op.weight: (i, op) for i, op in enumerate(prog.ops) if op.weight >= 0}
+    qscales: Dict[int, torch.Tensor] = {}
+    for wi, r in enumerate(prog.weights):
         if r.kind in ("conv", "stem", "bias"):
             if r.prefix not in folded:
                 folded[r.prefix] = fold_conv(sd, r, eps)
@@ -77,17 +87,36 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
                     if c % ce:
                         raise ValueError(f"{r.prefix}: input view of {c} channels is not a multiple of {ce} "
                                          f"({dtype} needs 16-byte channel chunks)")
-                out.append(pack_conv_weight(wf, dtype))
+                if dtype == "f8":
+                    import numpy as np
+                    from .quant import quantize_conv_weight
+                    oi, op = op_of_weight[wi]
+                    c0 = getattr(op, "swapped", 0)
+                    if c0:                                    # engine swapped the two views: same order for the weight columns
+                        wf = torch.cat([wf[:, c0:], wf[:, :c0]], 1)
+                    s_in = np.concatenate([quant.buf_scale[v.buf][v.ch_off:v.ch_off + v.ch_cnt] for v in op.src])
+                    q, qs = quantize_conv_weight(wf, s_in)
+                    qscales[oi] = qs
+                    out.append(q)
+                else:
+                    out.append(pack_conv_weight(wf, dtype))
             elif r.kind == "stem":
-                out.append(pack_stem_weight(wf, bgr_input, dtype))
+                out.append(pack_stem_weight(wf, bgr_input, "f16" if dtype == "f8" else dtype))
             else:
-                bp = torch.zeros(((bf.numel() + 127) // 128 * 128,), dtype=torch.float32)   # padded: the persistent
-                bp[:bf.numel()] = bf                                                        # conv kernel s_loads 16 at a time
-                out.append(bp)
+                out.append(_pad128(bf))
         elif r.kind == "linear":
             out.append(sd[r.prefix + ".weight"].float().contiguous())
         elif r.kind == "linear_bias":
             out.append(sd[r.prefix + ".bias"].float().contiguous())
         else:
             raise ValueError(r.kind)
-    return out
+    if dtype != "f8":
+        return out
+    extra = {}
+    for oi, qs in qscales.items():
+        op = prog.ops[oi]
+        bias = out[op.bias][:qs.numel()]
+        extra[oi] = (len(out), len(out) + 1)
+        out.append(_pad128(qs))
+        out.append(_pad128(bias / qs))
+    return out, extra
