@@ -236,6 +236,24 @@ int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, in
  * (tests/test_gpu_preprocess.py).  Stateless; errors through miyolo_last_error(NULL).  Asynchronous on `stream`. */
 int miyolo_crop_resize(const void* frame, int H, int W, const int32_t* boxes, int n, int size, int max_short, void* out, void* stream);
 
+/* Sliced ("SAHI-style") inference on the device (reference pipe.py:43-45,183-194 ->
+ * [3P] sahi.get_sliced_prediction with 640 x 640 slices, 20 % overlap).  miyolo_slice_batch cuts one device frame
+ * [H][W][3] into the batch out [n][sh][sw][3]: slice i = frame[y1:y2, x1:x2] (boxes int32 [n][4], inside the frame) at the
+ * top-left of its canvas, the rest pad_value (slices smaller than the canvas only at frames smaller than a slice).
+ * Stateless; errors through miyolo_last_error(NULL). */
+int miyolo_slice_batch(const void* frame, int H, int W, const int32_t* boxes, int n, void* out, int sh, int sw, int pad_value,
+                       void* stream);
+
+/* The merge step of sliced inference: the per-slice detections (dets float [n_slices][slice_max_det][6] in slice
+ * coordinates + counts, as miyolo_detect wrote them; boxes = the slice origins) are shifted into frame coordinates and
+ * merged by the SAME class-aware NMS as the per-frame post-process (score order, cls * 7680 offset unless agnostic, strict
+ * IoU > iou), keeping at most max_det.  H x W: any frame size the handle's workspace covers with at least
+ * n_slices * slice_max_det anchors (the slice size does).  y_scratch: device float [(4 + nc) * n_slices * slice_max_det].
+ * out_index (optional): for every kept box its candidate slot slice * slice_max_det + row. */
+int miyolo_merge_slices(miyolo_handle h, const float* dets, const int32_t* counts, const int32_t* boxes, int n_slices, int slice_max_det,
+                        int H, int W, float iou, int agnostic, int max_det, float* y_scratch, float* out_dets, int32_t* out_counts,
+                        int32_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

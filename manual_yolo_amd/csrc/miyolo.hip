@@ -806,7 +806,9 @@ int miyolo_nms(miyolo_handle h, const float* y, int B, int A, int H, int W, floa
   if (!y || !out_dets || !out_counts) return fail(h, MIYOLO_ERR_ARG, "null argument");
   if (max_det < 1 || max_det > 1024) return fail(h, MIYOLO_ERR_ARG, "max_det %d out of range [1,1024]", max_det);
   if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
-  if (A != h->plan.A) return fail(h, MIYOLO_ERR_SHAPE, "A=%d does not match the %d anchors of a %dx%d frame", A, h->plan.A, H, W);
+  // A < the frame's anchor count is allowed (candidate lists of the sliced-inference merge step): the key / class-index
+  // scratch is sized for plan.A
+  if (A < 1 || A > h->plan.A) return fail(h, MIYOLO_ERR_SHAPE, "A=%d exceeds the %d anchors of a %dx%d frame", A, h->plan.A, H, W);
   DevGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Plan& p = h->plan;
@@ -995,6 +997,36 @@ int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, in
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "letterbox launch: %s", hipGetErrorString(e));
   return 0;
+}
+
+int miyolo_slice_batch(const void* frame, int H, int W, const int32_t* boxes, int n, void* out, int sh, int sw, int pad_value, void* stream) {
+  if (!frame || !boxes || !out || H < 1 || W < 1 || n < 1 || sh < 1 || sw < 1 || pad_value < 0 || pad_value > 255)
+    return fail(nullptr, MIYOLO_ERR_ARG, "slice_batch: bad arguments");
+  SliceArgs a;
+  a.frame = static_cast<const uint8_t*>(frame); a.boxes = boxes; a.out = static_cast<uint8_t*>(out);
+  a.H = H; a.W = W; a.n = n; a.sh = sh; a.sw = sw; a.pad = pad_value;
+  hipLaunchKernelGGL(slice_batch_kernel, dim3((sw + 63) / 64, (sh + 3) / 4, n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "slice_batch launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int miyolo_merge_slices(miyolo_handle h, const float* dets, const int32_t* counts, const int32_t* boxes, int n_slices, int slice_max_det,
+                        int H, int W, float iou, int agnostic, int max_det, float* y_scratch, float* out_dets, int32_t* out_counts,
+                        int32_t* out_index, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 0) return fail(h, MIYOLO_ERR_ARG, "not a detection model");
+  if (!dets || !counts || !boxes || !y_scratch || !out_dets || !out_counts || n_slices < 1 || slice_max_det < 1)
+    return fail(h, MIYOLO_ERR_ARG, "merge_slices: null argument");
+  const int cap = n_slices * slice_max_det;
+  DevGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MergeArgs m;
+  m.dets = dets; m.counts = counts; m.boxes = boxes; m.y = y_scratch; m.ns = n_slices; m.max_det = slice_max_det; m.nc = h->desc.nc; m.cap = cap;
+  hipLaunchKernelGGL(merge_pack_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, m);
+  HIP_TRY(h, hipGetLastError());
+  // every candidate already passed its slice's confidence threshold: conf = 0 keeps all real ones (score > 0)
+  return miyolo_nms(h, y_scratch, 1, cap, H, W, 0.0f, iou, agnostic, max_det, nullptr, out_dets, out_counts, out_index, workspace, workspace_bytes, stream);
 }
 
 int miyolo_crop_resize(const void* frame, int H, int W, const int32_t* boxes, int n, int size, int max_short, void* out, void* stream) {

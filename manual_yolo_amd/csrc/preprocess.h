@@ -186,4 +186,61 @@ inline size_t crop_resize_lds_bytes(int S, int tmp_rows) {
   return (size_t)S * kCrKMax * 4 * 2 + (size_t)S * 2 * 4 * 2 + (size_t)tmp_rows * S * 3;
 }
 
+// ------------------------------------------------------------------------------------
+// Sliced ("SAHI-style") inference, SURVEY.md 8f rank 4 (reference pipe.py:43-45,183-194): cut one frame into a batch of
+// slices on the device.  out[i] = frame[y1:y2, x1:x2] placed at the top-left of an sh x sw canvas, the rest = pad.
+struct SliceArgs {
+  const uint8_t* frame;     // [H][W][3]
+  const int32_t* boxes;     // [n][4] x1,y1,x2,y2 (inside the frame)
+  uint8_t* out;             // [n][sh][sw][3]
+  int32_t H, W, n, sh, sw, pad;
+};
+
+__global__ __launch_bounds__(256) void slice_batch_kernel(const SliceArgs a) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int i = blockIdx.z;
+  if (x >= a.sw || y >= a.sh) return;
+  const int x1 = a.boxes[i * 4 + 0], y1 = a.boxes[i * 4 + 1], x2 = a.boxes[i * 4 + 2], y2 = a.boxes[i * 4 + 3];
+  uint8_t* o = a.out + (((size_t)i * a.sh + y) * a.sw + x) * 3;
+  const int fx = x1 + x, fy = y1 + y;
+  if (fx < x2 && fy < y2 && fx < a.W && fy < a.H) {
+    const uint8_t* p = a.frame + ((size_t)fy * a.W + fx) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+  } else {
+    o[0] = (uint8_t)a.pad; o[1] = (uint8_t)a.pad; o[2] = (uint8_t)a.pad;
+  }
+}
+
+// Candidate list -> the [1, 4+nc, n] layout miyolo_nms consumes: the boxes of all slices, shifted into frame coordinates,
+// become "anchors" whose only non-zero class score is the detection's confidence, so that the merge step is the SAME
+// class-aware NMS (sort, cls*7680 offset, IoU > thr) as the per-slice post-process.
+struct MergeArgs {
+  const float* dets;        // [ns][max_det][6] per-slice detections (slice coordinates)
+  const int32_t* counts;    // [ns]
+  const int32_t* boxes;     // [ns][4] slice origins (x1,y1,..)
+  float* y;                 // [1][4+nc][cap]
+  int32_t ns, max_det, nc, cap;
+};
+
+__global__ __launch_bounds__(256) void merge_pack_kernel(const MergeArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;           // candidate slot = slice * max_det + row
+  if (idx >= a.cap) return;
+  const int sl = idx / a.max_det, r = idx - sl * a.max_det;
+  const bool ok = sl < a.ns && r < a.counts[sl];
+  float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, cf = 0.f;
+  int cls = 0;
+  if (ok) {
+    const float* d = a.dets + ((size_t)sl * a.max_det + r) * 6;
+    const float ox = (float)a.boxes[sl * 4 + 0], oy = (float)a.boxes[sl * 4 + 1];
+    x1 = d[0] + ox; y1 = d[1] + oy; x2 = d[2] + ox; y2 = d[3] + oy; cf = d[4]; cls = (int)d[5];
+  }
+  // xywh such that the NMS kernel's xy -+ wh/2 reproduces the corners: (x1+x2)/2 and x2-x1 are exact halves / differences
+  a.y[0 * (size_t)a.cap + idx] = (x1 + x2) / 2.0f;
+  a.y[1 * (size_t)a.cap + idx] = (y1 + y2) / 2.0f;
+  a.y[2 * (size_t)a.cap + idx] = x2 - x1;
+  a.y[3 * (size_t)a.cap + idx] = y2 - y1;
+  for (int c = 0; c < a.nc; ++c) a.y[(size_t)(4 + c) * a.cap + idx] = (ok && c == cls) ? cf : 0.f;
+}
+
 }  // namespace miyolo

@@ -74,6 +74,8 @@ SYMBOLS = {
     "miyolo_debug_stamps": (_i, [_vp, _vp]),
     "miyolo_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "miyolo_crop_resize": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "miyolo_slice_batch": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "miyolo_merge_slices": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -297,6 +299,41 @@ class Engine:
                                  anchor.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
         self._check(rc, "miyolo_nms")
         return dets, counts, anchor
+
+    def detect_sliced(self, frame: torch.Tensor, boxes, slice_hw, conf: float = 0.25, iou: float = 0.7, agnostic: bool = False,
+                      max_det: int = 300, extra: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """One frame uint8 [H,W,3] (device) cut into slices `boxes` (list of x1,y1,x2,y2) of canvas slice_hw, ONE batched
+        miyolo_detect, boxes shifted back and merged by the class-aware NMS (miyolo_merge_slices).  `extra`: optional
+        (dets [1,max_det,6] in frame coordinates, counts [1]) of a full-frame pass to merge in as one more "slice" at (0,0).
+        Returns (dets [max_det,6] frame coordinates, count, index [max_det] = slice * max_det + row of every kept box)."""
+        if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3:
+            raise MiyoloError("frame must be uint8 [H,W,3]")
+        frame = frame.to(self.device).contiguous()
+        H, W = int(frame.shape[0]), int(frame.shape[1])
+        sh, sw = slice_hw
+        n = len(boxes)
+        bx = torch.tensor(boxes, dtype=torch.int32, device=self.device).reshape(n, 4)
+        batch = torch.empty((n, sh, sw, 3), dtype=torch.uint8, device=self.device)
+        if self.lib.miyolo_slice_batch(frame.data_ptr(), H, W, bx.data_ptr(), n, batch.data_ptr(), sh, sw, 114, self._stream()):
+            raise MiyoloError(f"miyolo_slice_batch failed: {self.lib.miyolo_last_error(None).decode()}")
+        dets, counts, _ = self.detect(batch, conf, iou, agnostic, max_det, None, want_anchor=False)
+        if extra is not None:
+            dets = torch.cat([dets, extra[0].to(self.device).reshape(1, max_det, 6)])
+            counts = torch.cat([counts, extra[1].to(self.device).reshape(1).to(torch.int32)])
+            bx = torch.cat([bx, torch.zeros((1, 4), dtype=torch.int32, device=self.device)])
+            n += 1
+        ws = self.workspace(n if extra is None else n - 1, sh, sw)
+        cap = n * max_det
+        if cap > self.num_anchors(sh, sw):
+            raise MiyoloError(f"{n} slices x max_det {max_det} exceed the {self.num_anchors(sh, sw)} candidate slots of a {sh}x{sw} workspace")
+        ysc = torch.empty(((4 + self.nc) * cap,), dtype=torch.float32, device=self.device)
+        od = torch.empty((1, max_det, 6), dtype=torch.float32, device=self.device)
+        oc = torch.empty((1,), dtype=torch.int32, device=self.device)
+        oi = torch.empty((1, max_det), dtype=torch.int32, device=self.device)
+        self._check(self.lib.miyolo_merge_slices(self.h, dets.contiguous().data_ptr(), counts.contiguous().data_ptr(), bx.data_ptr(), n, max_det, sh, sw,
+                                                 iou_threshold_f32(iou), int(agnostic), max_det, ysc.data_ptr(), od.data_ptr(), oc.data_ptr(),
+                                                 oi.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "miyolo_merge_slices")
+        return od[0], oc[0], oi[0]
 
     def classify(self, frames: torch.Tensor):
         """uint8 [B,H,W,3] -> (logits, probs) [B,nc] f32.  In graph mode the returned tensors are the engine's own

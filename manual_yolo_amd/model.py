@@ -81,6 +81,37 @@ class YOLO:
             return list(source)
         raise TypeError("source must be an HxWx3 BGR uint8 numpy array or a list of them")
 
+    def predict_sliced(self, source, slice_height: int = 640, slice_width: int = 640, overlap_height_ratio: float = 0.2,
+                       overlap_width_ratio: float = 0.2, conf: Optional[float] = None, iou: float = 0.7, max_det: int = 300,
+                       half: bool = False, agnostic_nms: bool = False, classes=None, perform_standard_pred: bool = True,
+                       imgsz=None) -> List[Results]:
+        """Sliced inference as the reference's ``run_sahi`` does it (``pipe.py:183-194``: 640 x 640 slices, 20 % overlap),
+        as ONE batched call: device-side slicing, one ``miyolo_detect`` over all slices, device-side merge (sahi.py).
+        ``perform_standard_pred`` (sahi's default): the full-frame prediction joins the candidates."""
+        from .sahi import slice_boxes
+        if self.task != "detect":
+            raise ValueError("sliced inference is a detection feature")
+        frames = self._as_frames(source)
+        eng = self.engine("f16" if half else "f32")
+        conf = 0.25 if conf is None else conf
+        out = []
+        for i, f in enumerate(frames):
+            H, W = f.shape[:2]
+            boxes = slice_boxes(H, W, slice_height, slice_width, overlap_height_ratio, overlap_width_ratio)
+            sh = (min(slice_height, H) + 31) // 32 * 32
+            sw = (min(slice_width, W) + 31) // 32 * 32
+            extra = None
+            eng.set_classes(classes)
+            if perform_standard_pred:
+                x = letterbox_batch_gpu([f], tuple((imgsz, imgsz) if isinstance(imgsz, int) else (imgsz or (self.meta["imgsz"],) * 2)), 32, auto=True, device=eng.device)
+                scale = torch.tensor([scale_params(tuple(x.shape[1:3]), (H, W))], dtype=torch.float32, device=eng.device)
+                d0, c0, _ = eng.detect(x, conf, iou, agnostic_nms, max_det, scale, want_anchor=False)
+                extra = (d0, c0)
+            d, c, idx = eng.detect_sliced(torch.from_numpy(np.ascontiguousarray(f)), boxes, (sh, sw), conf, iou, agnostic_nms, max_det, extra)
+            n = int(c)
+            out.append(Results(f, f"image{i}.jpg", self.names, boxes=d[:n].cpu().clone(), anchor_idx=idx[:n].cpu().clone()))
+        return out
+
     def predict(self, source=None, stream: bool = False, imgsz=None, conf: Optional[float] = None, iou: float = 0.7,
                 max_det: int = 300, half: bool = False, agnostic_nms: bool = False, classes=None,
                 verbose: bool = False, device=None, **unused) -> List[Results]:

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summarize import short  # noqa: E402
 
 root, out = sys.argv[1], sys.argv[2]
+workload = [int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]] if len(sys.argv) > 6 else [64, 640, 640, "f16"]
 acc = defaultdict(lambda: {"fetch": 0.0, "write": 0.0, "n_fetch": 0, "n_write": 0})
 for g, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for f in sorted(glob.glob(os.path.join(root, g, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:   # newest run only
@@ -29,7 +30,7 @@ for k, v in acc.items():
     kern[k] = {"launches": n, "fetch_bytes_per_launch": v["fetch"] / max(v["n_fetch"], 1),
                "write_bytes_per_launch": v["write"] / max(v["n_write"], 1),
                "traffic_bytes_per_launch": v["fetch"] / max(v["n_fetch"], 1) + v["write"] / max(v["n_write"], 1)}
-json.dump({"source": "tools/pmc_profile.sh + tools/pmc_traffic.py (bench.py --steps 2 --warmup 1, yolov8m 640x640 batch 64 f16); "
+json.dump({"workload": workload, "source": "tools/pmc_profile.sh + tools/pmc_traffic.py (bench.py --steps 2 --warmup 1, workload = [batch, H, W, dtype]); "
                      "separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled (gfx950 correction)",
            "kernels": kern}, open(out, "w"), indent=1)
 print("wrote", out, len(kern), "kernels")

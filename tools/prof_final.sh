@@ -1,11 +1,17 @@
 #!/bin/bash
 # Round-end evidence run (on the GPU box, via gpurun): rocprofv3 kernel stats of the default bench, the PMC passes,
-# the final bench lines (f16 with CPU baseline, f32, classifier) and the device pre-processing rates.
+# the bench lines (f16 default incl. parity / exact_f32 / CPU baseline, fp8 at 640 and at config 5's 1280x1280x16,
+# classifier) and the device pre-processing rates.   usage: bash tools/prof_final.sh <tag e.g. r02>
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_final.log 2>&1 && echo stats-ok
-cd $R && bash tools/pmc_profile.sh final > gpurun_out/pmc_final.log 2>&1; tail -2 gpurun_out/pmc_final.log
-timeout -k 10 400 python bench.py --profile-out gpurun_out/perop_final_f16.json > gpurun_out/final_f16.log 2>&1; tail -1 gpurun_out/final_f16.log | cut -c1-160
-timeout -k 10 300 python bench.py --dtype f32 --no-cpu-baseline --profile-out gpurun_out/perop_final_f32.json > gpurun_out/final_f32.log 2>&1; tail -1 gpurun_out/final_f32.log | cut -c1-160
-timeout -k 10 200 python bench.py --workload classify --no-cpu-baseline > gpurun_out/final_cls.log 2>&1; tail -1 gpurun_out/final_cls.log | cut -c1-160
-timeout -k 10 120 python tools/bench_preprocess.py > gpurun_out/final_pre.log 2>&1; tail -1 gpurun_out/final_pre.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-exact-f32 > $R/gpurun_out/prof_$TAG.log 2>&1 && echo stats-ok
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_f8 -- python3 $R/bench.py --dtype f8 --imgsz 1280 --batch 16 --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-exact-f32 > $R/gpurun_out/prof_${TAG}_f8.log 2>&1 && echo stats-f8-ok
+cd $R && bash tools/pmc_profile.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1; tail -2 gpurun_out/pmc_$TAG.log
+PMC_GROUPS="sq1 fetch write" bash tools/pmc_profile.sh ${TAG}_f8 --dtype f8 --imgsz 1280 --batch 16 > gpurun_out/pmc_${TAG}_f8.log 2>&1; tail -1 gpurun_out/pmc_${TAG}_f8.log
+timeout -k 10 500 python bench.py --profile-out gpurun_out/perop_${TAG}_f16.json > gpurun_out/${TAG}_f16.log 2>&1; tail -1 gpurun_out/${TAG}_f16.log | cut -c1-160
+timeout -k 10 300 python bench.py --dtype f32 --no-cpu-baseline --profile-out gpurun_out/perop_${TAG}_f32.json > gpurun_out/${TAG}_f32.log 2>&1; tail -1 gpurun_out/${TAG}_f32.log | cut -c1-160
+timeout -k 10 300 python bench.py --dtype f8 --no-cpu-baseline --no-exact-f32 --profile-out gpurun_out/perop_${TAG}_f8_640.json > gpurun_out/${TAG}_f8_640.log 2>&1; tail -1 gpurun_out/${TAG}_f8_640.log | cut -c1-160
+timeout -k 10 300 python bench.py --dtype f8 --imgsz 1280 --batch 16 --no-cpu-baseline --no-exact-f32 --profile-out gpurun_out/perop_${TAG}_f8_1280.json > gpurun_out/${TAG}_f8_1280.log 2>&1; tail -1 gpurun_out/${TAG}_f8_1280.log | cut -c1-160
+timeout -k 10 200 python bench.py --workload classify --no-cpu-baseline > gpurun_out/${TAG}_cls.log 2>&1; tail -1 gpurun_out/${TAG}_cls.log | cut -c1-160
+timeout -k 10 120 python tools/bench_preprocess.py > gpurun_out/${TAG}_pre.log 2>&1; tail -1 gpurun_out/${TAG}_pre.log
