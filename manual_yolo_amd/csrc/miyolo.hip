@@ -991,8 +991,8 @@ int miyolo_letterbox(const void* src, int B, int src_h, int src_w, void* dst, in
   a.src = static_cast<const uint8_t*>(src); a.dst = static_cast<uint8_t*>(dst);
   a.B = B; a.sh = src_h; a.sw = src_w; a.dh = dst_h; a.dw = dst_w; a.top = top; a.left = left; a.nh = new_h; a.nw = new_w;
   a.pad = pad_value;
-  a.scale_x = (double)src_w / (double)new_w;
-  a.scale_y = (double)src_h / (double)new_h;
+  a.scale_x = 1.0 / ((double)new_w / (double)src_w);      // OpenCV: scale = 1. / inv_scale, inv_scale = dsize / ssize
+  a.scale_y = 1.0 / ((double)new_h / (double)src_h);
   hipLaunchKernelGGL(letterbox_kernel, dim3((dst_w + 63) / 64, (dst_h + 3) / 4, B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "letterbox launch: %s", hipGetErrorString(e));

@@ -2,8 +2,8 @@
 //
 // letterbox_kernel: uint8 HWC frame(s) -> aspect-preserving INTER_LINEAR resize + constant pad, uint8 HWC.
 // Integer/byte work, bit-exact against the CPU restatement (oracle/pre_ref.py resize_linear_u8, which follows
-// cv2's 8-bit linear resize): per axis  f = (d + 0.5) * (sn / dn) - 0.5 in double,  s = floor(f),
-// frac = float(f - s), clamped at both ends, coefficients cvRound(frac * 2048) / cvRound((1 - frac) * 2048);
+// OpenCV's 8-bit linear resize - restated from its source, unverified against cv2): per axis
+// f = (float)((d + 0.5) * (1 / (dn / sn)) - 0.5),  s = floor(f),  frac = f - s (float), clamped at both ends, coefficients cvRound(frac * 2048) / cvRound((1 - frac) * 2048);
 // horizontal pass in int32, vertical pass  ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
 // One thread per output pixel (3 channels); HBM-bound, every source byte is read ~ (scale^-2) times through L2.
 #pragma once
@@ -20,9 +20,9 @@ struct LetterboxArgs {
 };
 
 __device__ __forceinline__ void lb_taps(int d, double scale, int sn, int* s0, int* s1, int* c0, int* c1) {
-  const double f = ((double)d + 0.5) * scale - 0.5;
-  int s = (int)floor(f);
-  float fr = (float)(f - (double)s);
+  const float f = (float)(((double)d + 0.5) * scale - 0.5);     // OpenCV: fx = (float)((dx + 0.5) * scale_x - 0.5)
+  int s = (int)floorf(f);                                       //         sx = cvFloor(fx); fx -= sx
+  float fr = f - (float)s;
   if (s < 0) { fr = 0.0f; s = 0; }
   if (s >= sn - 1) { fr = 0.0f; s = sn - 1; }
   *c1 = (int)rintf(fr * 2048.0f);

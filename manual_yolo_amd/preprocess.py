@@ -25,9 +25,10 @@ def bilinear_resize_u8(src: np.ndarray, dsize: Tuple[int, int]) -> np.ndarray:
     sh, sw = src.shape[:2]
 
     def taps(dn: int, sn: int):
-        pos = (np.arange(dn, dtype=np.float64) + 0.5) * (sn / dn) - 0.5
+        # OpenCV order: the coordinate is rounded to float first; floor and fraction both come from that float
+        pos = ((np.arange(dn, dtype=np.float64) + 0.5) * (1.0 / (dn / sn)) - 0.5).astype(np.float32)
         i0 = np.floor(pos).astype(np.int64)
-        frac = (pos - i0).astype(np.float32)
+        frac = (pos - i0.astype(np.float32)).astype(np.float32)
         under, over = i0 < 0, i0 >= sn - 1
         frac[under] = 0.0
         i0[under] = 0

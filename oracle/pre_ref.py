@@ -53,16 +53,22 @@ def _cv_round(x: np.ndarray) -> np.ndarray:
 
 
 def resize_linear_u8(src: np.ndarray, dsize: Tuple[int, int]) -> np.ndarray:
-    """cv2.resize(src, dsize=(w,h), interpolation=cv2.INTER_LINEAR) for uint8 HxWxC."""
+    """cv2.resize(src, dsize=(w,h), interpolation=cv2.INTER_LINEAR) for uint8 HxWxC - restated from OpenCV's source,
+    unverified against cv2 (not installed; no reference fixture)."""
     dw, dh = dsize
     sh, sw = src.shape[:2]
 
     def coeffs(dn, sn):
-        scale = sn / dn
+        # OpenCV resize.cpp (INTER_LINEAR, 8-bit): inv_scale = dsize / ssize; scale = 1. / inv_scale (doubles);
+        #   fx = (float)((dx + 0.5) * scale_x - 0.5);  sx = cvFloor(fx);  fx -= sx;
+        # i.e. the source coordinate is rounded to FLOAT first, and both the floor and the fraction come from that float.
+        # (cv2 is not installed here and the reference holds no resize fixture: restated from the published source,
+        # unverified against cv2 itself.)
+        scale = 1.0 / (dn / sn)
         d = np.arange(dn, dtype=np.float64)
-        f = (d + 0.5) * scale - 0.5
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
-        f = (f - s).astype(np.float32)
+        f = (f - s.astype(np.float32)).astype(np.float32)
         lo = s < 0
         f[lo] = 0; s[lo] = 0
         hi = s >= sn - 1

@@ -270,3 +270,75 @@ def test_fp16_mode_agrees_on_detections():
         od = {a: d for a, d in zip(idxs[b], outs[b])}
         for a in common:
             assert np.abs(gd[a][:4] - od[a][:4]).max() < 2.0 and abs(gd[a][4] - od[a][4]) < 2e-2
+
+
+@pytest.fixture(scope="module")
+def real_frames(golden_dir):
+    import os
+    return dict(np.load(os.path.join(golden_dir, "real_frames.npz")))
+
+
+def test_real_letterboxed_frames_yolov8m_fp32_identical_indices(real_frames):
+    """Config 3's real-frame leg: four letterboxed 1600x900 screenshots of the reference's validation set
+    (tests/golden/real_frames.npz, tools/make_frames_golden.py), 384x640 rect input, yolov8m fp32 mode: scores within
+    1e-4, kept anchor indices after NMS identical to the CPU path."""
+    sd, meta, eng = _model("m", "f32")
+    frames = real_frames["frames"]                       # BGR, as the reference passes them; synthetic weights have no colour preference
+    y, _ = _oracle(sd, "m", frames)
+    y = y.numpy()
+    x = torch.from_numpy(frames).cuda()
+    gy = eng.head_raw(x).cpu().numpy()
+    es, eb = np.abs(gy[:, 4:] - y[:, 4:]).max(), np.abs(gy[:, :4] - y[:, :4]).max()
+    print(f"real frames: max score err {es:.2e}, max box err {eb:.2e} px")
+    assert es < 1e-4 and eb < 5e-2          # boxes span up to 640 px: 0.03 px measured = 5e-5 relative
+    dets, counts, anchor = eng.detect(x, conf=0.25, iou=0.7)
+    outs, idxs = non_max_suppression(y, 0.25, 0.7)
+    gouts, gidxs = non_max_suppression(gy, 0.25, 0.7)            # oracle post-process on the GPU's own head output
+    for b in range(len(frames)):
+        n = int(counts[b])
+        ga = anchor[b, :n].cpu().numpy()
+        assert n == len(gidxs[b]) and np.array_equal(ga, gidxs[b]) and np.array_equal(dets[b, :n].cpu().numpy(), gouts[b])
+        # against the CPU path end to end: these frames saturate max_det (300 kept) with many near-equal scores; two correct
+        # fp32 evaluations (score difference <= 8e-5) may swap neighbours in the ranking - the same kept set up to such
+        # swaps: every position holds the same anchor, or one whose CPU score is within 2e-4 of the CPU's choice
+        assert n == len(idxs[b])
+        sc = y[b, 4:, :].max(0)
+        same = ga == idxs[b]
+        assert same.mean() > 0.97 and np.abs(sc[ga] - sc[idxs[b]])[~same].max(initial=0.0) < 2e-4
+        assert len(np.intersect1d(ga, idxs[b])) >= n - 3
+
+
+def test_nms_on_real_label_layouts_bit_exact(small, real_frames):
+    """NMS on box layouts taken from the reference's own labels (cards, buttons and text fields of a poker table: many
+    small boxes in rows, unlabel.py:44,54-57 label format): every labelled box becomes a cluster of jittered candidates of
+    its class plus distractors of other classes; kept indices / boxes / order bit-exact vs the oracle."""
+    sd, eng = small
+    H, W = 384, 640
+    A = eng.num_anchors(H, W)
+    rng = np.random.default_rng(9)
+    nf = int(real_frames["orig_hw"].shape[0])
+    y = np.zeros((nf, 4 + NC, A), np.float32)
+    y[:, 0] = rng.uniform(0, W, (nf, A)); y[:, 1] = rng.uniform(0, H, (nf, A)); y[:, 2:4] = rng.uniform(4, 30, (nf, 2, A))
+    y[:, 4:] = (rng.uniform(0, 1, (nf, NC, A)) ** 12).astype(np.float32) * 0.5          # background: few weak candidates
+    for f in range(nf):
+        rows = real_frames["label_rows"][real_frames["label_frame"] == f]
+        slots = rng.permutation(A)
+        k = 0
+        for (cls, cx, cy, w, h) in rows:
+            pad = (H - 360) / 2                                                         # 1600x900 -> 640x360 + 12 px bars
+            for j in range(24):                                                         # 24 jittered candidates per labelled box
+                a = slots[k]; k += 1
+                y[f, 0, a] = cx * 640 + rng.normal(0, 1.5); y[f, 1, a] = cy * 360 + pad + rng.normal(0, 1.5)
+                y[f, 2, a] = w * 640 * rng.uniform(0.9, 1.1); y[f, 3, a] = h * 360 * rng.uniform(0.9, 1.1)
+                y[f, 4:, a] = 0
+                y[f, 4 + int(cls) % NC, a] = rng.uniform(0.3, 0.99)
+                if j % 6 == 0:
+                    y[f, 4 + (int(cls) + 1) % NC, a] = rng.uniform(0.3, 0.99)           # a rival class on the same box
+    for agn in (False, True):
+        dets, counts, anchor = eng.nms(torch.from_numpy(y), H, W, 0.25, 0.7, agn, 300)
+        outs, idxs = non_max_suppression(y, 0.25, 0.7, agnostic=agn)
+        for b in range(nf):
+            n = int(counts[b])
+            assert n == len(idxs[b]) and n > 5
+            assert np.array_equal(anchor[b, :n].cpu().numpy(), idxs[b])
+            assert np.array_equal(dets[b, :n].cpu().numpy(), outs[b])
