@@ -53,7 +53,7 @@ inline void h2_geo(int geo, int* tw, int* th, int* hp) {
   *tw = geo == 1 ? 40 : geo == 2 ? 20 : 16; *th = geo == 1 ? 6 : geo == 2 ? 12 : 16; *hp = geo == 1 ? 48 : 24;
 }
 
-template <typename T, int TC, int GEO>
+template <typename T, int TC, int GEO, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const H2Geom g) {
   constexpr int TW = H2Geo<GEO>::TW, TH = H2Geo<GEO>::TH, HP = H2Geo<GEO>::HP;
   constexpr int GX = (TW + 2 + 7) / 8, NPX = TW * TH;
@@ -76,14 +76,24 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   const int frow = lane & 15, fq = lane >> 4;
   const int H = a.Hin, W = a.Win;
 
-  // ---- one tile per workgroup (the hardware's dynamic dispatch balanced better than static tile lists: persistent
-  // workgroups with the next tile's slab issued under the epilogue measured 3-10 % slower per layer); XCD-contiguous
-  // renumbering (bijective), channel tile fastest, so the channel tiles sharing a halo run side by side on one XCD
-  int L = blockIdx.x;
-  {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = L & 7, slot_ = L >> 3;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot_;
-  }
+  // ---- tiles of this workgroup.  Tiles are numbered channel tile fastest (the channel tiles sharing a halo are
+  // neighbours) and dealt to XCDs in contiguous chunks (workgroups b, b + 8, ... share an XCD and its L2).
+  //   !PERSIST: one tile per workgroup, grid = tiles (the hardware's dispatch balances).
+  //   PERSIST : grid = two workgroups per CU; workgroup (xcd, slot) walks its XCD's chunk with stride grid / 8, and the NEXT
+  //             tile's first slab is issued piecewise inside the epilogue (a workgroup's first slab costs 3-9 k cycles of
+  //             blocked DMA issue + 2.5 k of waiting at the head of a 55-75 k-cycle tile).  Measured (option "h2_warm" = 1):
+  //             the prologue shrinks from ~13 k to ~6 k cycles per tile, but the same DMAs cost ~270 cycles each inside the
+  //             epilogue - a slab that comes from beyond L2 is admitted at the CU's ~11 B/clk miss rate wherever its
+  //             DMAs are placed, and the issuing wave waits - and the static tile lists balance worse than the hardware's
+  //             dispatch: 1.4 % slower on the whole step.  Kept selectable and tested, off by default.
+  const int nblk = PERSIST ? g.ntiles : (int)gridDim.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
+  const int xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int xlen = xq + (xcd < xr ? 1 : 0);
+  const int xstride = PERSIST ? (int)(gridDim.x >> 3) : 1;
+  if (slot_ >= xlen) return;
+  int L = xstart + slot_;
+  int tleft = PERSIST ? (xlen - slot_ - 1) / xstride : 0;      // tiles after the first
 
   const v4i_t rs0 = make_srd(a.src[0].ptr, a.src[0].bytes);
   const v4i_t rsw = make_srd(a.w, a.wbytes);
@@ -164,6 +174,19 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
           lds_dma16(rs0, st + gx * 1024, ((mrow >> gx) & 1u) ? off : kOob);
         }
       }
+    }
+  };
+
+  // one DMA of a slab (piece q = i * GX + gx, compile-time): the next tile's slab goes out between the epilogue's blocks
+  auto issue_slab_piece = [&](const Tile& t, uint32_t msk, auto q_tag) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_tag)::value, i = q / GX, gx = q % GX;
+    const int hy = wave + 4 * i;
+    if (hy < TH + 2) {
+      const int y = t.y0 - 1 + hy;
+      const int32_t sb = ((t.bimg * H + y) * W + t.x0 - 1) * ldB;
+      const uint32_t mrow = (y >= 0 && y < H) ? msk : 0u;
+      const uint32_t off = (uint32_t)(((gx & 1) ? lc1 : lc0) + sb + gx * 8 * ldB);
+      lds_dma16(rs0, lds_base + (uint32_t)(hy * HP * ROW_BYTES) + gx * 1024, ((mrow >> gx) & 1u) ? off : kOob);
     }
   };
 
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 #endif
 
   // ---- K loop: chunk outermost; per tap one barrier, the next tap's weights in flight under this tap's MFMAs
-  const Tile cur = tile_coords(L);
+  Tile cur = tile_coords(L);
   set_w(cur.n0);
   set_x(cur.x0);
 #if MIYOLO_ABLATE
@@ -260,13 +283,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   issue_slab(cur, 0);
   issue_w(0, 0, 0);
   STAMP(p1);
-  init_acc(cur.n0);
-#if MIYOLO_ABLATE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  STAMP(p2);
-#endif
   int slot = 0;
-  {
+  for (;;) {
+    const bool has_next = PERSIST && tleft > 0;
+    Tile nxt = cur;
+    init_acc(cur.n0);
+#if MIYOLO_ABLATE
+    if (n_tiles == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(p2); }
+#endif
     // The tap loop is a real loop over dy with dx unrolled - NOT nine unrolled taps: the fully unrolled kernel was 60-80 KB
     // of code for an instruction cache of 64 KB shared by two CUs (four resident workgroups at different places of it),
     // and every layer ran 10-15 % slower than with a third of the code.
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
         STAMP(s1);                                                                                  \
         if (dy * 3 + (DX) < 8) issue_w(c, dy * 3 + (DX) + 1, slot ^ 1);                             \
         else if (more) issue_w(c + 1, 0, slot ^ 1);                                                 \
+        else if (has_next) { nxt = tile_coords(L + xstride); set_w(nxt.n0); issue_w(0, 0, slot ^ 1); } \
         STAMP(s2);                                                                                  \
         compute(dyoff, std::integral_constant<int, DX>{}, slot, full);                              \
         STAMP(s3);                                                                                  \
@@ -303,7 +328,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
     }
     STAMP(s4);
 
-    // ---- epilogue (activation, residual, 8 channels per store)
+    // ---- epilogue (activation, residual, 8 channels per store).  PERSIST: between its blocks the NEXT tile's first slab
+    // goes out one DMA at a time - the queue drains while the VALU works, nobody blocks, and the slab has landed when
+    // the next tile starts.  All residual loads are issued BEFORE the first of those DMAs (vmcnt retires in order: a
+    // load behind a slab DMA would wait for HBM).
     int32_t mpix[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
@@ -312,78 +340,125 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       const int y = cur.y0 + py, x = cur.x0 + p - py * TW;
       mpix[j] = (p < NPX && y < H && x < W) ? (cur.bimg * H + y) * W + x : -1;
     }
+    constexpr int NBLK = NPAIR * TPW + ((TC & 1) ? TPW : 0);       // epilogue blocks
+    constexpr int NPIECE = RPW * GX;                                  // DMAs of a slab per wave
+    uint32_t nmsk = 0;
+    if (has_next) {
+      asm volatile("s_barrier" ::: "memory");                         // every wave is done with the slab of `cur`
+      xmask = 0;
+      set_x(nxt.x0);
+      nmsk = xmask & ((cg0 * CE < a.cin ? 0x55555555u : 0u) | ((cg0 ^ 4) * CE < a.cin ? 0xAAAAAAAAu : 0u));
+    }
+    // Without a residual operand the slab's DMAs are spread over all blocks; with one, over the blocks behind the last
+    // residual loads only (a load issued behind a slab DMA would wait for it: vmcnt retires in order).
+    constexpr int KRES = (NPAIR > 0 ? (NPAIR - 1) * TPW : 0);          // first block behind the last pair's residual loads
+    auto pieces_after_block = [&](auto k_tag) __attribute__((always_inline)) {
+      constexpr int k = decltype(k_tag)::value;
+      if constexpr (PERSIST) {
+        if (has_next) {
+          if (!a.res) {
+            constexpr int q0 = k * NPIECE / NBLK, q1 = (k + 1) * NPIECE / NBLK;
+            static_assert(q1 - q0 <= 3, "more than three slab DMAs per epilogue block");
+            if constexpr (q1 > q0) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0>{});
+            if constexpr (q1 > q0 + 1) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 1>{});
+            if constexpr (q1 > q0 + 2) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 2>{});
+          } else if constexpr (k >= KRES) {
+            constexpr int nb = NBLK - KRES, kk = k - KRES;
+            constexpr int q0 = kk * NPIECE / nb, q1 = (kk + 1) * NPIECE / nb;
+            static_assert(q1 - q0 <= 6, "more than six slab DMAs per epilogue block");
+            if constexpr (q1 > q0) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0>{});
+            if constexpr (q1 > q0 + 1) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 1>{});
+            if constexpr (q1 > q0 + 2) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 2>{});
+            if constexpr (q1 > q0 + 3) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 3>{});
+            if constexpr (q1 > q0 + 4) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 4>{});
+            if constexpr (q1 > q0 + 5) issue_slab_piece(nxt, nmsk, std::integral_constant<int, q0 + 5>{});
+          }
+        }
+      }
+    };
+    v2i_t rlast[TPW];
+    if constexpr ((TC & 1) && ES != 4) {                 // the unpaired channel tile's residual: with the first loads
+      if (a.res) {
+        const int n = cur.n0 + 16 * (TC - 1) + 4 * fq;
 #pragma unroll
-    for (int ip = 0; ip < NPAIR; ++ip) {
+        for (int j = 0; j < TPW; ++j) {
+          const uint32_t ro = (n < a.cout && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+          if constexpr (ES == 2) rlast[j] = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
+          else rlast[j] = (v2i_t){(int)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0), 0};
+        }
+      }
+    }
+    auto pair_block = [&](auto ip_tag, auto j_tag, const float (&qm)[8], const v4ie_t (&rrow)[TPW]) __attribute__((always_inline)) {
+      constexpr int ip = decltype(ip_tag)::value, j = decltype(j_tag)::value;
       const int n = cur.n0 + 32 * ip + 8 * fq;
-      const bool nok = n < a.cout;
-      v4ie_t r0[TPW], r1[TPW];
+      const bool ok = n < a.cout && mpix[j] >= 0;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = act(acc[2 * ip][j][r] * qm[r]); v[4 + r] = act(acc[2 * ip + 1][j][r] * qm[4 + r]); }
+      if (a.res) {
+        if constexpr (ES == 1) {
+          float ra[4], rb[4];
+          unpack_fp8x4((uint32_t)rrow[j][0], ra); unpack_fp8x4((uint32_t)rrow[j][1], rb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = fmaf(ra[r], a.res_scale, v[r]); v[4 + r] = fmaf(rb[r], a.res_scale, v[4 + r]); }
+        } else if constexpr (ES == 4) {
+          const uint32_t ro = ok ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+          const v4ie_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rres, ro + 16u, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] += __int_as_float(q0[r]); v[4 + r] += __int_as_float(q1[r]); }
+        } else {
+          const f16x8 hr = *reinterpret_cast<const f16x8*>(&rrow[j]);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
+        }
+      }
+      const uint32_t so = ok ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
+      if constexpr (ES == 1) {
+        const float q = a.out_inv_scale;
+        const v2i_t o = {(int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), (int)pack_fp8x4(v[4] * q, v[5] * q, v[6] * q, v[7] * q)};
+        __builtin_amdgcn_raw_buffer_store_b64(o, rdst, so, 0, 0);
+      } else if constexpr (ES == 4) {
+        const v4ie_t o0 = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+        const v4ie_t o1 = {__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, rdst, so + 16u, 0, 0);
+      } else {
+        const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, 0);
+      }
+      pieces_after_block(std::integral_constant<int, ip * TPW + j>{});
+    };
+    auto pair_row = [&](auto ip_tag) __attribute__((always_inline)) {
+      constexpr int ip = decltype(ip_tag)::value;
       float qm[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-      if constexpr (ES == 1) {             // fp8: per-channel dequantisation scale of this lane's 8 channels; residual bytes
+      if constexpr (ES == 1) {             // fp8: per-channel dequantisation scale of this lane's 8 channels
+        const int n = cur.n0 + 32 * ip + 8 * fq;
         const v4ie_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rqs, (uint32_t)(n * 4), 0, 0);
         const v4ie_t q1 = __builtin_amdgcn_raw_buffer_load_b128(rqs, (uint32_t)(n * 4 + 16), 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { qm[r] = __int_as_float(q0[r]); qm[4 + r] = __int_as_float(q1[r]); }
-        if (a.res) {
+      }
+      v4ie_t rrow[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) rrow[j] = (v4ie_t){0, 0, 0, 0};
+      if constexpr (ES != 4) {
+        if (a.res) {                         // the four residual loads of this channel pair in flight together
+          const int n = cur.n0 + 32 * ip + 8 * fq;
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
-            const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)(mpix[j] * a.res_ld + a.res_choff + n) : kOob;
-            const v2i_t rr = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
-            r0[j] = (v4ie_t){rr[0], rr[1], 0, 0};
+            const uint32_t ro = (n < a.cout && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
+            if constexpr (ES == 2) rrow[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+            else { const v2i_t rr = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0); rrow[j] = (v4ie_t){rr[0], rr[1], 0, 0}; }
           }
         }
       }
-      if constexpr (ES == 2) {
-        if (a.res) {                     // f16: the four residual loads of a channel pair in flight together
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) {
-            const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
-            r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        if constexpr (ES == 4) {
-          if (a.res) {                   // f32 (parity mode): one pixel at a time keeps the register count down
-            const uint32_t ro = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
-            r0[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
-            r1[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro + 16u, 0, 0);
-          }
-        }
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] = act(acc[2 * ip][j][r] * qm[r]); v[4 + r] = act(acc[2 * ip + 1][j][r] * qm[4 + r]); }
-        if (a.res) {
-          if constexpr (ES == 1) {
-            float ra[4], rb[4];
-            unpack_fp8x4((uint32_t)r0[j][0], ra); unpack_fp8x4((uint32_t)r0[j][1], rb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = fmaf(ra[r], a.res_scale, v[r]); v[4 + r] = fmaf(rb[r], a.res_scale, v[4 + r]); }
-          } else if constexpr (ES == 4) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] += __int_as_float(r0[j][r]); v[4 + r] += __int_as_float(r1[j][r]); }
-          } else {
-            const f16x8 hr = *reinterpret_cast<const f16x8*>(&r0[j]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
-          }
-        }
-        const uint32_t so = (nok && mpix[j] >= 0) ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
-        if constexpr (ES == 1) {
-          const float q = a.out_inv_scale;
-          const v2i_t o = {(int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), (int)pack_fp8x4(v[4] * q, v[5] * q, v[6] * q, v[7] * q)};
-          __builtin_amdgcn_raw_buffer_store_b64(o, rdst, so, 0, 0);
-        } else if constexpr (ES == 4) {
-          const v4ie_t o0 = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
-          const v4ie_t o1 = {__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(o1, rdst, so + 16u, 0, 0);
-        } else {
-          const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, 0);
-        }
-      }
-    }
+      pair_block(ip_tag, std::integral_constant<int, 0>{}, qm, rrow); pair_block(ip_tag, std::integral_constant<int, 1>{}, qm, rrow);
+      pair_block(ip_tag, std::integral_constant<int, 2>{}, qm, rrow); pair_block(ip_tag, std::integral_constant<int, 3>{}, qm, rrow);
+    };
+    if constexpr (NPAIR > 0) pair_row(std::integral_constant<int, 0>{});
+    if constexpr (NPAIR > 1) pair_row(std::integral_constant<int, 1>{});
+    if constexpr (NPAIR > 2) pair_row(std::integral_constant<int, 2>{});
+    static_assert(NPAIR <= 3 && TPW == 4, "epilogue rows are written out for up to three channel-tile pairs of four pixel tiles");
     if constexpr (TC & 1) {                              // unpaired last channel tile: 4 channels per lane
       constexpr int i = TC - 1;
       const int n = cur.n0 + 16 * i + 4 * fq;
@@ -394,26 +469,25 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) qm[r] = __int_as_float(q0[r]);
       }
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
+      auto last_block = [&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = act(acc[i][j][r] * qm[r]);
         const bool ok = nok && mpix[j] >= 0;
         if (a.res) {
-          const uint32_t ro = ok ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
           if constexpr (ES == 1) {
             float ra[4];
-            unpack_fp8x4((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0), ra);
+            unpack_fp8x4((uint32_t)rlast[j][0], ra);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaf(ra[r], a.res_scale, v[r]);
           } else if constexpr (ES == 4) {
+            const uint32_t ro = ok ? (uint32_t)((mpix[j] * a.res_ld + a.res_choff + n) * ES) : kOob;
             const v4ie_t rr = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += __int_as_float(rr[r]);
           } else {
-            const v2i_t rr = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
-            const f16x4 hr = *reinterpret_cast<const f16x4*>(&rr);
+            const f16x4 hr = *reinterpret_cast<const f16x4*>(&rlast[j]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += (float)hr[r];
           }
@@ -429,12 +503,19 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
           const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
           __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
         }
-      }
+        pieces_after_block(std::integral_constant<int, NPAIR * TPW + j>{});
+      };
+      last_block(std::integral_constant<int, 0>{}); last_block(std::integral_constant<int, 1>{});
+      last_block(std::integral_constant<int, 2>{}); last_block(std::integral_constant<int, 3>{});
     }
     STAMP(s5);
 #if MIYOLO_ABLATE
-    acc_epi += s5 - s4; n_tiles = 1;
+    acc_epi += s5 - s4; ++n_tiles;
 #endif
+    if (!has_next) break;
+    cur = nxt;
+    L += xstride;
+    --tleft;
   }
 #undef H2_ACC
 #if MIYOLO_ABLATE
@@ -444,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
     d[0] = s5 - s_begin; d[1] = acc_wait; d[2] = acc_issue; d[3] = acc_comp; d[4] = acc_slab; d[5] = acc_epi;
     d[6] = (unsigned long long)g.nchunk * 9 * n_tiles; d[7] = acc_slabbar + 1;
     unsigned long long* e = a.dbg + 16384 + ((size_t)blockIdx.x * 4 + wave) * 4;
-    e[0] = p0 - s_begin; e[1] = p1 - p0; e[2] = p2 - p1; e[3] = s_begin;
+    e[0] = p0 - s_begin; e[1] = p1 - p0; e[2] = p2 - p1; e[3] = n_tiles;
   }
 #endif
 }
@@ -523,27 +604,38 @@ inline bool h2_eligible(const ConvArgs& a, double min_util) {
   return h2_geometry<T>(a, &g, &lds, &tc, &geo) && h2_util(g, a.Hout, a.Wout) >= min_util;
 }
 
-template <typename T, int TC>
-inline void launch_h2_geo(const ConvArgs& a, const H2Geom& g, int geo, size_t lds, hipStream_t s) {
-  const dim3 grid((unsigned)g.ntiles), blk(256);
+template <typename T, int TC, bool PERSIST>
+inline void launch_h2_geo(const ConvArgs& a, const H2Geom& g, int geo, size_t lds, hipStream_t s, unsigned nwg) {
+  const dim3 grid(nwg), blk(256);
   switch (geo) {
-    case 1: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 1>), grid, blk, lds, s, a, g); break;
-    case 2: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 2>), grid, blk, lds, s, a, g); break;
-    default: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 0>), grid, blk, lds, s, a, g); break;
+    case 1: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 1, PERSIST>), grid, blk, lds, s, a, g); break;
+    case 2: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 2, PERSIST>), grid, blk, lds, s, a, g); break;
+    default: hipLaunchKernelGGL((conv_h2_kernel<T, TC, 0, PERSIST>), grid, blk, lds, s, a, g); break;
   }
+}
+template <typename T, int TC>
+inline void launch_h2_tc(const ConvArgs& a, const H2Geom& g, int geo, size_t lds, hipStream_t s, int ncu, int persist) {
+  // persistent form: two workgroups per CU, every XCD chunk walked with stride grid / 8; only worth it (and only built)
+  // for the 16 / 8-bit types and when there is more than one tile per workgroup slot
+  if constexpr (sizeof(T) != 4) {
+    if (persist && g.ntiles > 2 * ncu) {
+      const unsigned nwg = (unsigned)((2 * ncu + 7) / 8 * 8);
+      launch_h2_geo<T, TC, true>(a, g, geo, lds, s, nwg);
+      return;
+    }
+  }
+  launch_h2_geo<T, TC, false>(a, g, geo, lds, s, (unsigned)g.ntiles);
 }
 
 template <typename T>
-inline hipError_t launch_conv_h2(const ConvArgs& a, hipStream_t s, int ncu, int warm = 1) {
+inline hipError_t launch_conv_h2(const ConvArgs& a, hipStream_t s, int ncu, int warm = 1) {     // warm: 1 = persistent form where it applies
   H2Geom g; size_t lds; int tc, geo;
   if (!h2_geometry<T>(a, &g, &lds, &tc, &geo)) return hipErrorInvalidValue;
-  g.warm = warm;
-  (void)ncu;
   switch (tc) {
-    case 3: launch_h2_geo<T, 3>(a, g, geo, lds, s); break;
-    case 4: launch_h2_geo<T, 4>(a, g, geo, lds, s); break;
+    case 3: launch_h2_tc<T, 3>(a, g, geo, lds, s, ncu, warm); break;
+    case 4: launch_h2_tc<T, 4>(a, g, geo, lds, s, ncu, warm); break;
     default:
-      if constexpr (!is_fp8<T>::value) launch_h2_geo<T, 6>(a, g, geo, lds, s);
+      if constexpr (!is_fp8<T>::value) launch_h2_tc<T, 6>(a, g, geo, lds, s, ncu, warm);
       else return hipErrorInvalidValue;
       break;
   }
@@ -554,8 +646,11 @@ template <typename T>
 inline hipError_t set_h2_attrs() {
   hipError_t e;
 #define MIYOLO_H2_ATTR(TC, GEO)                                                                         \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<T, TC, GEO>),               \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kH2LdsMax)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<T, TC, GEO, false>),        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kH2LdsMax)) != hipSuccess) return e; \
+  if constexpr (sizeof(T) != 4) {                                                                         \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<T, TC, GEO, true>),       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kH2LdsMax)) != hipSuccess) return e; }
   MIYOLO_H2_ATTR(3, 0) MIYOLO_H2_ATTR(4, 0) MIYOLO_H2_ATTR(3, 1) MIYOLO_H2_ATTR(4, 1) MIYOLO_H2_ATTR(3, 2) MIYOLO_H2_ATTR(4, 2)
   if constexpr (!is_fp8<T>::value) { MIYOLO_H2_ATTR(6, 0) MIYOLO_H2_ATTR(6, 1) MIYOLO_H2_ATTR(6, 2) }
 #undef MIYOLO_H2_ATTR

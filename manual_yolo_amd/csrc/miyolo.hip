@@ -68,7 +68,7 @@ struct miyolo_engine {
   int dmh_auto = 0;         // conv_impl 3: two-workgroup kernel for launches with 1-2 tiles per CU (conv_dmh.h); off since the
                             // balanced grids: +0.2 % without it (same-box A/B), it won only by removing a half-empty round
   int h2 = 1;               // conv_impl 3: 3x3 stride-1 layers on the halo-slab kernel (conv_h2.h) where its tiles cover the map well
-  int h2_warm = 1;          // ... with the L2 warm-up of the next channel chunk's slab
+  int h2_warm = 0;          // ... 1: persistent form (next tile's slab issued inside the epilogue): measured 1.4 % SLOWER on the step, off
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
