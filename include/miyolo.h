@@ -185,7 +185,9 @@ int miyolo_chunk(miyolo_handle h, int B, int H, int W);
  * 2-D-tile kernel), "dmh_auto" (0 default: conv_impl 3 hands launches with 1-2 tiles per CU to
  * kernel 6), "ncu" (width of the persistent grids, default = the device's CU count), "graph"
  * (1: detect/classify calls are captured into a hipGraph and replayed while shape, thresholds,
- * stream and pointers stay the same; needs a non-default stream; default 0), and the
+ * stream and pointers stay the same; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
+ * "h2_min_util" percent (70) of the map; "h2_warm" = 1 selects its persistent form), "cls_streams" (1 default:
+ * > 1 makes miyolo_classify fork the batch over that many internal streams, joined by events - measured slower), and the
  * timing-experiment switches "ablate" / "dbg_op" of the non-shipped builds.  Setting any option
  * drops the captured graphs. */
 int miyolo_set_option(miyolo_handle h, const char* key, int value);

@@ -268,3 +268,19 @@ def test_h2_channel_slices(dtype):
     ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
     assert rel_err(y[..., 96:96 + cout], ref) < TOL[dtype]
     assert np.all(y[..., :96] == 7.0) and np.all(y[..., 96 + cout:] == 7.0)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B,res", [(96, 96, 80, 80, 22, True), (192, 192, 40, 40, 40, False), (64, 64, 80, 80, 24, True)])
+def test_h2_persistent_variant(cin, cout, H, W, B, res):
+    """conv_h2.h's persistent form (option h2_warm = 1, off by default): more tiles than the 512 workgroup slots, the next
+    tile's slab issued inside the epilogue, with and without a residual operand; f16, vs torch and vs the default form."""
+    dtype = "f16"
+    rng = np.random.default_rng(cin + cout + B)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype) if res else None
+    yp = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=8, opts={"h2_warm": 1})
+    y0 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=8)
+    assert rel_err(yp, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
+    assert np.array_equal(yp, y0)          # same arithmetic in both forms
