@@ -175,6 +175,11 @@ int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, flo
  * offsets suffice and, optionally, so that activations stay cache resident). */
 int miyolo_chunk(miyolo_handle h, int B, int H, int W);
 
+/* Kernel launches one miyolo_classify() call of H x W crops enqueues under the current options: 1 when the one-launch
+ * classifier (csrc/cls_mega.h) serves that size, else the layer count.  lds_bytes (may be NULL) receives the LDS one
+ * workgroup (= one image) of the one-launch kernel holds, 0 for the layered path.  < 0: error. */
+int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
+
 /* Options: "max_chunk" (images per pass, 0 = automatic), "force_wc"/"force_tc" (pin the conv
  * tile shape: waves along channels 1|2, 16-channel tiles per wave 1..6; tests and tuning),
  * "profile" (see miyolo_profile_read), "conv_impl" (0: register-staged double-buffered conv
@@ -186,7 +191,8 @@ int miyolo_chunk(miyolo_handle h, int B, int H, int W);
  * kernel 6), "ncu" (width of the persistent grids, default = the device's CU count), "graph"
  * (1: detect/classify calls are captured into a hipGraph and replayed while shape, thresholds,
  * stream and pointers stay the same; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
- * "h2_min_util" percent (70) of the map; "h2_warm" = 1 selects its persistent form), "cls_streams" (1 default:
+ * "h2_min_util" percent (70) of the map; "h2_warm" = 1 selects its persistent form), "cls_mega" (1 default: an f16 classifier whose activations fit LDS runs as ONE launch, cls_mega.h; 0: one launch per
+ * layer; bit-identical results), "cls_streams" (1 default:
  * > 1 makes miyolo_classify fork the batch over that many internal streams, joined by events - measured slower), and the
  * timing-experiment switches "ablate" / "dbg_op" of the non-shipped builds.  Setting any option
  * drops the captured graphs. */

@@ -1,0 +1,398 @@
+// The whole yolov8n-cls forward as ONE launch: one workgroup per image, every activation of the image resident in LDS.
+//
+// Why (BASELINE config 2, SURVEY.md 8d: "in practice launch-bound; use one persistent kernel"): the layered path runs the
+// classifier (reference detect.py:121 `rank_model(crop)`) as 27 dependent launches of 1-3 us of work each, and the GPU's
+// front end spends ~8.5 us per dependent dispatch: 0.23 ms per batch of 256 whatever the kernels do (hipGraph replay and
+// multi-stream forks measured slower).  A 64 x 64 crop's activations are tiny - 32 KiB after the stem, 177 KiB
+// summed over all 20 buffers, 72 KiB alive at once - so a workgroup keeps its image's buffers in LDS (the host packs them
+// by liveness), walks the layer table and only streams the weights (2.9 MB f16, L2 resident) through registers:
+//   * 8 waves; a conv's work items are (16-channel tile, group of up to four 16-pixel tiles) pairs dealt to the waves;
+//     an item's K loop loads ONE weight fragment per 32-deep step straight from global/L2 (16 B per lane, eight
+//     steps in flight) and uses it for up to four MFMAs, the activation fragments are 16-byte LDS reads addressed per lane
+//     (3x3 taps, stride 2 and channel slices are address arithmetic; buffers read by a 3x3 conv carry a zero halo, and
+//     pixels are padded by 16 bytes so that a fragment read is free of bank conflicts);
+//   * same MFMA (16x16x32 f16), same K order (tap, channel), same epilogue arithmetic (acc + bias -> SiLU -> + residual ->
+//     f16) as the layered f16 kernels: logits are BIT-IDENTICAL to the layered path (tests/test_gpu_cls.py);
+//   * the Classify tail (avg-pool, Linear, softmax) runs in the same launch with the arithmetic order of cls_head_kernel.
+// f16 only (config 2's dtype); the exact-fp32 parity mode and models that do not fit keep the layered path.
+#pragma once
+#include "common.h"
+#include "conv_igemm.h"
+#include "conv_dma.h"
+
+namespace miyolo {
+
+struct MegaOp {
+  int32_t kind, ksize, stride, act;
+  int32_t cin, cout, kpad, lg_cpt;          // lg_cpt: log2(cin / 8) for 3x3 convs
+  int32_t hout, wout, lg_wout;
+  // LDS views: org = byte offset of pixel (0,0), first channel of the view; wp = pixels per stored row (width + 2 when the
+  // buffer carries a zero halo); ps = bytes per stored pixel (channels * 2 + 16: an odd number of 16-byte chunks, so the 16
+  // pixels of a fragment read land in 16 different bank groups instead of one)
+  int32_t src_org, src_wp, src_ps;
+  int32_t dst_org, dst_wp, dst_ps;
+  int32_t res_org, res_wp, res_ps;          // res_org < 0: no residual
+  int32_t zero_off, zero_rows;              // first writer of a haloed buffer clears its halo ring: buffer offset, stored rows
+  int32_t wbytes;
+  const void* w;                            // [cout][kpad] f16 (stem: [cout][32], K' order of kernels_misc.h)
+  const float* bias;
+};
+
+constexpr int kMegaMaxOps = 30;
+constexpr int kMegaPf = 8;                  // weight fragments in flight per wave
+constexpr int kMegaWaves = 8;               // 512 threads per image
+
+struct MegaArgs {
+  const uint8_t* in;                        // [B][H][W][3]
+  float* logits; float* probs;              // [B][nc] (either may be null)
+  const float* lin_w; const float* lin_b;   // Classify.linear
+  int32_t B, H, W, nc, nops;
+  int32_t feat_off, feat_c, feat_hw, feat_ps;   // the Classify conv's output in LDS (no halo)
+  int32_t pool_off;                         // fp32 scratch for pooled features + logits
+  int32_t ring_off;                         // kMegaWaves weight rings of kMegaPf KiB
+  unsigned long long* stamps;               // option dbg_op: cycle counter after every layer, first 8 images x 32 slots
+  MegaOp ops[kMegaMaxOps];
+};
+
+// A wave's weight stream: a private LDS ring of kMegaPf slots (1 KiB = 64 lanes x 16 B each) always holds the next kMegaPf K
+// steps the wave will consume - of the current item, then of its next item, then of its first item of the NEXT layer - so
+// layer boundaries, epilogues and barriers overlap the L2 latency.  The fills are LDS-DMA loads written as inline asm with
+// hand-counted waits: every visit of a slot waits vmcnt(kMegaPf - 1) (the slot's own fill is the oldest in flight),
+// optionally computes, and issues EXACTLY ONE new fill into the slot, so the count never changes.  Nothing else in a conv
+// layer uses VMEM: the bias comes through the scalar cache.
+//   Measured on the way here (batch 256): compiler-visible register loads made the waitcnt pass put vmcnt(0) in front of
+//   every MFMA (600-2000 cycles per K step, 0.21-0.29 ms per batch); asm loads into registers are not usable, the register
+//   allocator copies a ring register (loop phi) while its load is still in flight.
+struct MegaStream {
+  v4i_t rs;
+  uint32_t arow;                            // byte offset of this lane's 16 bytes of step 0
+  int nsteps;                               // 0: no such item
+};
+constexpr uint32_t kMegaOob = 0x80000000u;  // offset past any weight tensor: the load returns zeros
+
+__device__ __forceinline__ void mega_load(uint32_t slot_addr, const v4i_t rs, uint32_t off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(slot_addr), "v"(off), "s"(rs) : "memory", "m0");
+}
+__device__ __forceinline__ void mega_wait_slot() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf - 1) : "memory"); }
+__device__ __forceinline__ void mega_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ MegaStream mega_first_item(const MegaOp& nx, bool has, int wave, int lane) {
+  const int frow = lane & 15, kq = lane >> 4;
+  const int mt = (nx.hout * nx.wout + 15) / 16, nt = nx.cout / 16, ng = (mt + 3) / 4;
+  MegaStream st;
+  st.rs = make_srd(nx.w, (uint32_t)nx.wbytes);
+  const int n_t = wave / ng;
+  st.arow = (uint32_t)(((n_t * 16 + frow) * nx.kpad + 8 * kq) * 2);
+  st.nsteps = (has && nx.kind == 1 && wave < nt * ng) ? nx.kpad / 32 : 0;
+  return st;
+}
+
+// (re)start the ring
+__device__ __forceinline__ void mega_prefetch(const MegaStream& st, uint32_t ring) {
+#pragma unroll
+  for (int u = 0; u < kMegaPf; ++u) mega_load(ring + u * 1024, st.rs, (u < st.nsteps) ? st.arow + (uint32_t)(u * 64) : kMegaOob);
+}
+
+__device__ __forceinline__ void mega_stem(const MegaArgs& a, const MegaOp& op, unsigned char* smem, int img, int wave, int lane) {
+  // conv3x3 s2 on the uint8 image as one 32-deep MFMA step per 16 output pixels (K' order: kernels_misc.h stem_kernel).
+  // The image bytes come from HBM: a wave loads the bytes of up to kStemTb of its tiles before it computes the first.
+  constexpr int kStemTb = 8;
+  const int frow = lane & 15, q = lane >> 4;
+  const uint8_t* im = a.in + (size_t)img * a.H * a.W * 3;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, (uint32_t)(a.H * a.W * 3), 0x00020000);
+  const int W3 = a.W * 3;
+  const int startq = (q < 3) ? q * W3 : 8, stepq = (q < 3) ? 1 : W3;
+  const uint32_t m_always = (q < 3) ? 0u : 0xF8u, m_top = (q < 3) ? (q == 0 ? 0xFFu : 0u) : 1u, m_left = (q < 3) ? 7u : 0u;
+  const int M = op.hout * op.wout, mt = (M + 15) / 16, ntc = op.cout / 16;
+  const half_t* wp = reinterpret_cast<const half_t*>(op.w);
+  const uint4 wf0 = *reinterpret_cast<const uint4*>(wp + frow * 32 + q * 8);
+  const float4 b0 = *reinterpret_cast<const float4*>(op.bias + q * 4);
+  for (int t0 = wave; t0 < mt; t0 += kMegaWaves * kStemTb) {
+    uint32_t ub[kStemTb][8];
+#pragma unroll
+    for (int i = 0; i < kStemTb; ++i) {
+      const int m = (t0 + i * kMegaWaves) * 16 + frow;
+      const bool vm = m < M;
+      const int mm = vm ? m : 0;
+      const int ho = mm >> op.lg_wout, wo = mm & (op.wout - 1);
+      const int rb = ((2 * ho - 1) * a.W + 2 * wo - 1) * 3;
+      const uint32_t inval = (vm ? m_always : 0xFFu) | (ho == 0 ? m_top : 0u) | (wo == 0 ? m_left : 0u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t off = (uint32_t)(rb + startq + j * stepq) | (((inval >> j) & 1u) << 31);
+        ub[i][j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kStemTb; ++i) {
+      const int m = (t0 + i * kMegaWaves) * 16 + frow;
+      const bool vm = m < M;
+      const int ho = m >> op.lg_wout, wo = m & (op.wout - 1);
+      f16x8 xb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = (half_t)((float)ub[i][j] * (1.0f / 255.0f));
+      for (int tc = 0; tc < ntc; ++tc) {
+        uint4 wf = wf0;
+        float4 bb = b0;
+        if (tc > 0) {
+          wf = *reinterpret_cast<const uint4*>(wp + (tc * 16 + frow) * 32 + q * 8);
+          bb = *reinterpret_cast<const float4*>(op.bias + tc * 16 + q * 4);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&wf), xb, acc, 0, 0, 0);
+        if (vm) {
+          const int n = tc * 16 + q * 4;
+          const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float y = acc[r] + bv[r];
+            if (op.act) y = silu_fast(y);
+            v[r] = y;
+          }
+          const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<f16x4*>(smem + op.dst_org + (ho * op.dst_wp + wo) * op.dst_ps + n * 2) = hv;
+        }
+      }
+    }
+  }
+}
+
+// Per-item constants of the K loop
+struct MegaItem {
+  v4i_t rsw, rs_n;                          // weight tensor of this item / of the item the ring moves on to
+  uint32_t arow, arow_n;
+  int nsteps, nsteps_n;
+  int ksize, lg_cpt, cptm, cpt1, src_wp, src_ps;
+};
+
+// byte offset of this lane's 8-channel chunk of K step ks from the tile's tap-(0,0) pixel.  No bounds tests: out-of-image
+// taps read the buffer's zero halo; chunks in the zero tail of K (weights are 0 there), and the one step past the end the
+// read-ahead touches, are clamped onto a real chunk so they multiply / read finite data
+__device__ __forceinline__ int mega_toff(const MegaItem& it, int ks, int kq) {
+  const int q = ks * 4 + kq;
+  if (it.ksize == 3) {
+    const int tap = min(q >> it.lg_cpt, 8);
+    const int dy = (tap * 11) >> 5;                                    // tap / 3 for tap < 12
+    const int dx = tap - 3 * dy;
+    return (dy * it.src_wp + dx) * it.src_ps + (q & it.cptm) * 16;
+  }
+  return min(q, it.cpt1) * 16;
+}
+
+// One turn of the ring: slots 0..NU-1 hold K steps k0..k0+NU-1 of the item and are consumed; every slot is then refilled
+// (the ring's rotation stays uniform, which is what makes the hand-counted vmcnt exact).  Branch-free: NPT pixel tiles per
+// weight fragment, the activation fragments of the next step are read before the MFMAs of this one.
+template <int NPT, int NU>
+__device__ __forceinline__ void mega_block(const MegaItem& it, const unsigned char* smem, const int (&base)[4], int kq, int k0,
+                                           uint32_t ring, int lane, f32x4 (&acc)[4], uint4 (&bf)[4]) {
+#pragma unroll
+  for (int u = 0; u < kMegaPf; ++u) {
+    const int ks = k0 + u;
+    mega_wait_slot();
+    if (u < NU) {
+      const uint4 af = *reinterpret_cast<const uint4*>(smem + ring + u * 1024 + lane * 16);
+      const int tn = mega_toff(it, ks + 1, kq);
+      uint4 bn[4];
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) bn[j] = *reinterpret_cast<const uint4*>(smem + base[j] + tn);
+#pragma unroll
+      for (int j = 0; j < NPT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&af), *reinterpret_cast<const f16x8*>(&bf[j]), acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) bf[j] = bn[j];
+    }
+    // slot u is free: step ks + kMegaPf of this item, or - past its end - step u of the wave's next item
+    const int t = ks + kMegaPf;
+    const bool cur = t < it.nsteps;
+    const uint32_t off = cur ? it.arow + (uint32_t)(t * 64) : ((u < it.nsteps_n) ? it.arow_n + (uint32_t)(u * 64) : kMegaOob);
+    mega_load(ring + u * 1024, cur ? it.rsw : it.rs_n, off);
+  }
+}
+
+template <int NPT>
+__device__ __forceinline__ void mega_kloop(const MegaItem& it, const unsigned char* smem, const int (&base)[4], int kq,
+                                           uint32_t ring, int lane, f32x4 (&acc)[4]) {
+  uint4 bf[4];
+  const int t0 = mega_toff(it, 0, kq);
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) bf[j] = *reinterpret_cast<const uint4*>(smem + base[j] + t0);
+  int k0 = 0;
+  for (; k0 + kMegaPf <= it.nsteps; k0 += kMegaPf) mega_block<NPT, kMegaPf>(it, smem, base, kq, k0, ring, lane, acc, bf);
+  switch (it.nsteps - k0) {                                            // K is padded to 64: the step count is even
+    case 2: mega_block<NPT, 2>(it, smem, base, kq, k0, ring, lane, acc, bf); break;
+    case 4: mega_block<NPT, 4>(it, smem, base, kq, k0, ring, lane, acc, bf); break;
+    case 6: mega_block<NPT, 6>(it, smem, base, kq, k0, ring, lane, acc, bf); break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ void mega_conv(const MegaOp& op, const MegaStream& nx, unsigned char* smem, int wave, int lane,
+                                          uint32_t ring, unsigned long long* fine) {
+  typedef const float __attribute__((address_space(4))) cfloat_t;     // constant address space: uniform loads go through SMEM
+  const int frow = lane & 15, kq = lane >> 4;
+  const int M = op.hout * op.wout, mt = (M + 15) / 16, nt = op.cout / 16, ng = (mt + 3) / 4;
+  const int nitems = nt * ng;
+  const int pad = op.ksize == 3 ? 1 : 0;
+  if (wave >= nitems) {                                                // idle in this layer: fetch for the next one
+    mega_prefetch(nx, ring);
+    return;
+  }
+  MegaItem it;
+  it.rsw = make_srd(op.w, (uint32_t)op.wbytes);
+  it.nsteps = op.kpad / 32;
+  it.ksize = op.ksize; it.lg_cpt = op.lg_cpt; it.cptm = (1 << op.lg_cpt) - 1; it.cpt1 = op.cin / 8 - 1;
+  it.src_wp = op.src_wp; it.src_ps = op.src_ps;
+  for (int item = wave; item < nitems; item += kMegaWaves) {
+    const int n_t = item / ng, g = item - n_t * ng;
+    const int n = n_t * 16 + kq * 4;                                   // lane's 4 output channels (C/D map of the 16x16 MFMA)
+    cfloat_t* bp = (cfloat_t*)(unsigned long long)(op.bias + n_t * 16);
+    float bs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs[i] = bp[i];
+    // what the ring fetches once this item's steps are all in flight
+    const bool more = item + kMegaWaves < nitems;
+    const int n_tn = (item + kMegaWaves) / ng;
+    it.arow = (uint32_t)(((n_t * 16 + frow) * op.kpad + 8 * kq) * 2);
+    it.arow_n = more ? (uint32_t)(((n_tn * 16 + frow) * op.kpad + 8 * kq) * 2) : nx.arow;
+    it.nsteps_n = more ? it.nsteps : nx.nsteps;
+    it.rs_n = more ? it.rsw : nx.rs;
+    int base[4], pdst[4];
+    bool pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = (4 * g + j) * 16 + frow;
+      pv[j] = p < M;
+      const int pp = pv[j] ? p : 0;                                    // columns past the image compute on pixel 0, never stored
+      const int oy = pp >> op.lg_wout, ox = pp & (op.wout - 1);
+      base[j] = op.src_org + ((oy * op.stride - pad) * op.src_wp + (ox * op.stride - pad)) * op.src_ps;   // tap (0,0)
+      pdst[j] = oy * op.dst_wp + ox;
+    }
+    const int npt = min(4, mt - 4 * g);                                // pixel tiles of this group (wave-uniform)
+    if (fine && item == wave && lane == 0) fine[1] = __builtin_readcyclecounter();
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (npt == 1) mega_kloop<1>(it, smem, base, kq, ring, lane, acc);
+    else mega_kloop<4>(it, smem, base, kq, ring, lane, acc);                   // 2 or 3 tiles: the others recompute pixel 0, never stored
+    // epilogue: lane holds channels n..n+3 of pixel p
+    if (fine && item == wave && lane == 0) fine[2] = __builtin_readcyclecounter();
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = kq == 0 ? bs[r] : kq == 1 ? bs[4 + r] : kq == 2 ? bs[8 + r] : bs[12 + r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < npt && pv[j]) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[j][r] + bv[r];
+          if (op.act) x = silu_fast(x);
+          v[r] = x;
+        }
+        if (op.res_org >= 0) {
+          const int p = (4 * g + j) * 16 + frow;
+          const int rp = (p >> op.lg_wout) * op.res_wp + (p & (op.wout - 1));
+          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + op.res_org + rp * op.res_ps + n * 2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)h[r];
+        }
+        const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<f16x4*>(smem + op.dst_org + pdst[j] * op.dst_ps + n * 2) = hv;
+      }
+    }
+  }
+}
+
+// workgroup barrier for LDS traffic only: no vmcnt wait, the weight ring stays in flight across it
+__device__ __forceinline__ void mega_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(kMegaWaves * 64) void cls_mega_kernel(const MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (a.stamps && img < 8 && tid == 0) a.stamps[img * 32 + 31] = __builtin_readcyclecounter();
+  const uint32_t ring = (uint32_t)(a.ring_off + wave * (kMegaPf * 1024));   // this wave's weight ring
+  MegaOp op = a.ops[0];
+  for (int oi = 0; oi < a.nops; ++oi) {
+    const bool has = oi + 1 < a.nops;
+    const MegaOp nxo = a.ops[has ? oi + 1 : oi];                         // descriptor of the next layer, fetched a layer ahead
+    const MegaStream nx = mega_first_item(nxo, has, wave, lane);
+    if (op.zero_rows > 0) {
+      // a buffer a 3x3 conv will read starts its life: clear its halo ring (disjoint from what this layer writes)
+      const int hp = op.zero_rows, wp = op.dst_wp, cps = op.dst_ps >> 4;
+      const int nbp = 2 * wp + 2 * (hp - 2);
+      for (int i = tid; i < nbp * cps; i += kMegaWaves * 64) {
+        const int b = i / cps, c = i - b * cps;
+        int row, col;
+        if (b < wp) { row = 0; col = b; }
+        else if (b < 2 * wp) { row = hp - 1; col = b - wp; }
+        else { const int r = b - 2 * wp; row = 1 + (r >> 1); col = (r & 1) ? wp - 1 : 0; }
+        *reinterpret_cast<uint4*>(smem + op.zero_off + (row * wp + col) * op.dst_ps + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if (op.kind == 0) { mega_stem(a, op, smem, img, wave, lane); mega_prefetch(nx, ring); }
+    else {
+      unsigned long long* fine = (a.stamps && img == 0 && wave == 0) ? a.stamps + 256 + oi * 4 : nullptr;
+      if (fine && lane == 0) fine[0] = __builtin_readcyclecounter();
+      mega_conv(op, nx, smem, wave, lane, ring, fine);
+      if (fine && lane == 0) fine[3] = __builtin_readcyclecounter();
+    }
+    mega_barrier();
+    if (a.stamps && img < 8 && tid == 0) a.stamps[img * 32 + oi] = __builtin_readcyclecounter();
+    op = nxo;
+  }
+  mega_drain();
+  // ---- Classify tail (arithmetic order of cls_head_kernel): avg-pool -> Linear -> softmax
+  float* pooled = reinterpret_cast<float*>(smem + a.pool_off);
+  float* lg = pooled + a.feat_c;
+  const half_t* f = reinterpret_cast<const half_t*>(smem + a.feat_off);
+  constexpr int kLin = 20;                                               // Linear weights of the wave's first class, in registers
+  float wv[kLin];
+  const bool wreg = a.feat_c <= kLin * 64;
+  if (wreg) {
+#pragma unroll
+    for (int i = 0; i < kLin; ++i) {
+      const int ch = lane + 64 * i;
+      wv[i] = (wave < a.nc && ch < a.feat_c) ? a.lin_w[(long)wave * a.feat_c + ch] : 0.f;
+    }
+  }
+  for (int ch = tid; ch < a.feat_c; ch += kMegaWaves * 64) {
+    float s = 0.f;
+    for (int p = 0; p < a.feat_hw; ++p) s += (float)f[p * (a.feat_ps / 2) + ch];
+    pooled[ch] = s / (float)a.feat_hw;
+  }
+  __syncthreads();
+  for (int k = wave; k < a.nc; k += kMegaWaves) {
+    const float* wr = a.lin_w + (long)k * a.feat_c;
+    float s = 0.f;
+    if (wreg && k == wave) {
+#pragma unroll
+      for (int i = 0; i < kLin; ++i) { const int ch = lane + 64 * i; if (ch < a.feat_c) s = fmaf(pooled[ch], wv[i], s); }
+    } else {
+      for (int ch = lane; ch < a.feat_c; ch += 64) s = fmaf(pooled[ch], wr[ch], s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) lg[k] = s + a.lin_b[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = lg[0];
+    for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, lg[k]);
+    float s = 0.f;
+    for (int k = 0; k < a.nc; ++k) s += expf(lg[k] - mx);
+    for (int k = 0; k < a.nc; ++k) {
+      if (a.logits) a.logits[(long)img * a.nc + k] = lg[k];
+      if (a.probs) a.probs[(long)img * a.nc + k] = expf(lg[k] - mx) / s;
+    }
+    if (a.stamps && img < 8) a.stamps[img * 32 + 30] = __builtin_readcyclecounter();
+  }
+}
+
+}  // namespace miyolo

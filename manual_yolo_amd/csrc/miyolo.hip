@@ -32,6 +32,7 @@
 #include "conv_dmh.h"
 #endif
 #include "kernels_misc.h"
+#include "cls_mega.h"
 #include "nms.h"
 #include "preprocess.h"
 
@@ -74,6 +75,10 @@ struct miyolo_engine {
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
   int dbg_op = -1;          // op index whose stamps are wanted
+  int cls_mega = 1;         // classify, f16: the whole forward as one launch with LDS-resident activations (cls_mega.h)
+  MegaArgs mega;            // layer table of that launch for the cached frame size
+  int mega_h = 0, mega_w = 0, mega_ok = 0;
+  size_t mega_lds = 0;
   int cls_streams = 1;      // classify: sub-batches on this many internal streams, joined by events.  Measured at batch 256: 1 stream
                             // 1.12 M img/s, 2: 0.85 M, 4: 0.40 M, 8: 0.29 M (captured in a hipGraph: 0.88 / 0.84 / 0.57 / 0.42 M) - the
                             // front end takes ~8 us per dispatch whether or not the chains are independent; only fewer launches help
@@ -595,6 +600,108 @@ void drop_graphs(miyolo_engine* h) {
   h->graphs.clear();
 }
 
+// Layer table + LDS packing of the one-launch classifier (cls_mega.h) for H x W crops; false: not applicable.
+bool build_mega(miyolo_engine* h, int H, int W) {
+  h->mega_h = H; h->mega_w = W; h->mega_ok = 0;
+  if (h->desc.task != 1 || h->desc.dtype != MIYOLO_F16 || (int)h->ops.size() > kMegaMaxOps + 1) return false;
+  const int nops = (int)h->ops.size();
+  if (nops < 2 || h->ops[0].kind != MIYOLO_OP_STEM || h->ops[nops - 1].kind != MIYOLO_OP_CLS_HEAD) return false;
+  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; };
+  // liveness of every activation buffer over the op sequence
+  const int nb = (int)h->bufs.size();
+  std::vector<int> first(nb, -1), last(nb, -1);
+  auto touch = [&](int b, int i) { if (b > 0) { if (first[b] < 0) first[b] = i; last[b] = i; } };
+  for (int i = 0; i < nops; ++i) {
+    const miyolo_op& op = h->ops[i];
+    if (op.kind == MIYOLO_OP_CONV || op.kind == MIYOLO_OP_STEM || op.kind == MIYOLO_OP_CLS_HEAD)
+      for (int k = 0; k < (op.kind == MIYOLO_OP_CONV ? op.n_src : 1); ++k) touch(op.src[k].buf, i);
+    if (op.kind != MIYOLO_OP_CLS_HEAD) touch(op.dst.buf, i);
+    if (op.kind == MIYOLO_OP_CONV && op.res.buf >= 0) touch(op.res.buf, i);
+  }
+  // stored layout of a buffer: pixels padded to an odd number of 16-byte chunks; a zero halo when a 3x3 conv reads it
+  std::vector<int> halo(nb, 0), ps(nb, 0), wp(nb, 0);
+  for (int i = 0; i < nops; ++i)
+    if (h->ops[i].kind == MIYOLO_OP_CONV && h->ops[i].ksize == 3 && h->ops[i].src[0].buf > 0) halo[h->ops[i].src[0].buf] = 1;
+  std::vector<size_t> off(nb, 0), size(nb, 0);
+  for (int b = 1; b < nb; ++b) {
+    const int hb = H / h->bufs[b].down, wb = W / h->bufs[b].down, c = h->bufs[b].channels;
+    if (c % 8) return false;
+    ps[b] = c * 2 + ((c / 8) % 2 == 0 ? 16 : 0);
+    wp[b] = wb + 2 * halo[b];
+    size[b] = (size_t)(hb + 2 * halo[b]) * wp[b] * ps[b];
+  }
+  auto org = [&](int b, int choff) { return (int)off[b] + halo[b] * (wp[b] + 1) * ps[b] + choff * 2; };
+  size_t peak = 0;
+  for (int i = 0; i < nops; ++i)
+    for (int b = 1; b < nb; ++b) {
+      if (first[b] != i) continue;
+      size_t cand = 0;                                // lowest offset that does not overlap a buffer alive at op i
+      for (bool moved = true; moved;) {
+        moved = false;
+        for (int o = 1; o < nb; ++o)
+          if (o != b && first[o] >= 0 && first[o] <= i && last[o] >= i && (first[o] < i || o < b) && cand < off[o] + size[o] && off[o] < cand + size[b]) {
+            cand = off[o] + size[o]; moved = true;
+          }
+      }
+      off[b] = cand;
+      peak = std::max(peak, cand + size[b]);
+    }
+  MegaArgs& m = h->mega;
+  memset(&m, 0, sizeof(m));
+  m.H = H; m.W = W; m.nc = h->desc.nc; m.nops = nops - 1;
+  for (int i = 0; i < nops - 1; ++i) {
+    const miyolo_op& op = h->ops[i];
+    MegaOp& o = m.ops[i];
+    const int db = op.dst.buf;
+    if (db <= 0) return false;
+    const miyolo_buf& ob = h->bufs[db];
+    if (ob.dtype != -1 || op.cout % 16 || op.dst.ch_off % 4) return false;
+    o.kind = op.kind == MIYOLO_OP_STEM ? 0 : 1; o.ksize = op.ksize; o.stride = op.stride; o.act = op.act;
+    o.cin = op.cin; o.cout = op.cout;
+    o.hout = H / ob.down; o.wout = W / ob.down; o.lg_wout = ilog2(o.wout);
+    if (o.lg_wout < 0) return false;
+    o.dst_org = org(db, op.dst.ch_off); o.dst_wp = wp[db]; o.dst_ps = ps[db];
+    if (halo[db] && first[db] == i) { o.zero_off = (int)off[db]; o.zero_rows = H / ob.down + 2; }
+    o.res_org = -1;
+    o.w = h->weights[op.weight]; o.bias = static_cast<const float*>(h->weights[op.bias]);
+    if (op.kind == MIYOLO_OP_STEM) {
+      if (ob.down != 2 || op.dst.ch_off != 0) return false;
+      o.kpad = 32; o.wbytes = op.cout * 32 * 2;
+      continue;
+    }
+    if (op.kind != MIYOLO_OP_CONV || op.n_src != 1 || op.src[0].upsample || op.src[0].buf <= 0) return false;
+    const int sbi = op.src[0].buf;
+    const miyolo_buf& sb = h->bufs[sbi];
+    if (op.cin % 8 || op.src[0].ch_off % 8) return false;
+    if (o.hout * op.stride != H / sb.down || o.wout * op.stride != W / sb.down) return false;
+    o.src_org = org(sbi, op.src[0].ch_off); o.src_wp = wp[sbi]; o.src_ps = ps[sbi];
+    const int K = op.cin * op.ksize * op.ksize;
+    o.kpad = (K + 63) / 64 * 64; o.wbytes = op.cout * o.kpad * 2;
+    o.lg_cpt = 0;
+    if (op.ksize == 3) { o.lg_cpt = ilog2(op.cin / 8); if (o.lg_cpt < 0) return false; }
+    else if (op.ksize != 1 || op.stride != 1) return false;
+    if (op.res.buf >= 0) {
+      const int rbi = op.res.buf;
+      if (rbi <= 0 || op.res.ch_off % 4) return false;
+      o.res_org = org(rbi, op.res.ch_off); o.res_wp = wp[rbi]; o.res_ps = ps[rbi];
+    }
+  }
+  const miyolo_op& hd = h->ops[nops - 1];
+  const miyolo_buf& fb = h->bufs[hd.src[0].buf];
+  if (hd.src[0].ch_off != 0 || fb.channels != hd.cin) return false;
+  if (halo[hd.src[0].buf]) return false;
+  m.feat_off = (int)off[hd.src[0].buf]; m.feat_c = hd.cin; m.feat_hw = (H / fb.down) * (W / fb.down); m.feat_ps = ps[hd.src[0].buf];
+  m.pool_off = (int)align_up(peak, 16);
+  peak = m.pool_off + (size_t)(hd.cin + hd.cout) * 4;
+  m.ring_off = (int)align_up(peak, 1024);
+  peak = m.ring_off + (size_t)kMegaWaves * kMegaPf * 1024;
+  m.lin_w = static_cast<const float*>(h->weights[hd.weight]); m.lin_b = static_cast<const float*>(h->weights[hd.bias]);
+  if (peak > 160 * 1024) return false;
+  h->mega_lds = peak;
+  h->mega_ok = 1;
+  return true;
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -687,6 +794,8 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_halo_attrs<half_t>();
 #endif
   if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(cls_mega_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_greedy_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, nms_lds_bytes(1024));
   if (e != hipSuccess) {
@@ -708,6 +817,17 @@ void miyolo_destroy(miyolo_handle h) {
 
 const char* miyolo_last_error(miyolo_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes) {
+  if (!h) return MIYOLO_ERR_ARG;
+  if (h->desc.task != 1) return fail(h, MIYOLO_ERR_ARG, "not a classify engine");
+  if (lds_bytes) *lds_bytes = 0;
+  if (h->cls_mega && !h->profile && h->desc.dtype == MIYOLO_F16) {
+    if (h->mega_h != H || h->mega_w != W) build_mega(h, H, W);
+    if (h->mega_ok) { if (lds_bytes) *lds_bytes = h->mega_lds; return 1; }
+  }
+  return (int)h->ops.size();
+}
+
 int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!h || !key) return MIYOLO_ERR_ARG;
   drop_graphs(h);                                    // every option can change which kernels a call launches
@@ -723,6 +843,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
+  if (!strcmp(key, "cls_mega")) { h->cls_mega = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }
   if (!strcmp(key, "h2_min_util")) { h->h2_min_util = value; return 0; }
@@ -857,6 +978,16 @@ int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Plan& p = h->plan;
   const int nc = h->desc.nc;
+  if (h->cls_mega && !h->profile && h->desc.dtype == MIYOLO_F16) {
+    if (h->mega_h != H || h->mega_w != W) build_mega(h, H, W);
+    if (h->mega_ok) {
+      MegaArgs m = h->mega;
+      m.in = in; m.logits = logits; m.probs = probs; m.B = B; m.stamps = h->dbg;
+      hipLaunchKernelGGL(cls_mega_kernel, dim3((unsigned)B), dim3(kMegaWaves * 64), h->mega_lds, s, m);
+      HIP_TRY(h, hipGetLastError());
+      return 0;
+    }
+  }
   const int Bs = cls_lane_batch(h, B);
   if (Bs > 0 && Bs <= auto_chunk(h, Bs, H, W)) {
     // fork / join on events (no host synchronisation): lane i runs images [i*Bs, (i+1)*Bs) in its own slice of the workspace

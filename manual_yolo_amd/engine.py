@@ -59,6 +59,7 @@ SYMBOLS = {
     "miyolo_last_error": (C.c_char_p, [_vp]),
     "miyolo_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "miyolo_chunk": (_i, [_vp, _i, _i, _i]),
+    "miyolo_classify_launches": (_i, [_vp, _i, _i, C.POINTER(_sz)]),
     "miyolo_set_option": (_i, [_vp, C.c_char_p, _i]),
     "miyolo_set_classes": (_i, [_vp, _vp, _i]),
     "miyolo_detect": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -243,6 +244,14 @@ class Engine:
 
     def chunk(self, B: int, H: int, W: int) -> int:
         return self.lib.miyolo_chunk(self.h, B, H, W)
+
+    def classify_launches(self, H: int, W: int) -> Tuple[int, int]:
+        """(kernel launches per classify() call of HxW crops, LDS bytes per image of the one-launch kernel or 0)."""
+        lds = _sz(0)
+        n = self.lib.miyolo_classify_launches(self.h, H, W, C.byref(lds))
+        if n < 0:
+            self._check(n, "classify_launches")
+        return n, int(lds.value)
 
     def _in(self, frames: torch.Tensor) -> Tuple[torch.Tensor, int, int, int]:
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:

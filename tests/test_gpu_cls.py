@@ -130,3 +130,25 @@ def test_hip_graph_replay_matches_direct_launches(rank_bundles, rank_valid):
     eng.set_option("graph", 0)
     l4, _ = eng.classify(x)
     assert torch.equal(l4, l0)
+
+
+@pytest.mark.parametrize("B", [1, 67, 256])
+def test_one_launch_classifier_is_bit_identical_to_the_layered_path(rank_bundles, rank_valid, B):
+    """cls_mega.h (default for f16): the whole forward in one launch with LDS-resident activations must give the SAME bits
+    as the 27-launch layered path (same MFMA, K order and epilogue arithmetic), and the reference's 63/67."""
+    from manual_yolo_amd.engine import engine_from_weights
+    sd, meta = rank_bundles["best"]
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    pre = rank_valid["pre_u8"]
+    idx = np.arange(B) % len(pre)
+    x = torch.from_numpy(pre[idx]).cuda()
+    n1, lds = eng.classify_launches(x.shape[1], x.shape[2])
+    assert n1 == 1 and 0 < lds <= 160 * 1024, "the one-launch kernel must serve config 2's crops"
+    l1, p1 = eng.classify(x)
+    l1, p1 = l1.clone(), p1.clone()
+    eng.set_option("cls_mega", 0)
+    assert eng.classify_launches(x.shape[1], x.shape[2])[0] > 20
+    l0, p0 = eng.classify(x)
+    assert torch.equal(l0, l1) and torch.equal(p0, p1)
+    if B >= 67:
+        assert int((p1[:67].argmax(1).cpu().numpy() == rank_valid["labels"]).sum()) == 63
