@@ -34,12 +34,13 @@ struct MegaOp {
   int32_t res_org, res_wp, res_ps;          // res_org < 0: no residual
   int32_t zero_off, zero_rows;              // first writer of a haloed buffer clears its halo ring: buffer offset, stored rows
   int32_t wbytes;
-  const void* w;                            // [cout][kpad] f16 (stem: [cout][32], K' order of kernels_misc.h)
+  const void* w;                            // convs: fragment order [cout/16][kpad/32][lane 64][8] f16 (mega_repack_kernel), one
+                                            // contiguous KiB per wave and K step; stem: [cout][32], K' order of kernels_misc.h
   const float* bias;
 };
 
 constexpr int kMegaMaxOps = 30;
-constexpr int kMegaPf = 8;                  // weight fragments in flight per wave
+constexpr int kMegaPf = 4;                  // weight fragments in flight per wave (ring slots; 4 KiB is what one M0 reaches)
 constexpr int kMegaWaves = 8;               // 512 threads per image
 
 struct MegaArgs {
@@ -50,6 +51,7 @@ struct MegaArgs {
   int32_t feat_off, feat_c, feat_hw, feat_ps;   // the Classify conv's output in LDS (no halo)
   int32_t pool_off;                         // fp32 scratch for pooled features + logits
   int32_t ring_off;                         // kMegaWaves weight rings of kMegaPf KiB
+  int32_t bias_off;                         // kMegaWaves x 2 bias slots of 256 B
   unsigned long long* stamps;               // option dbg_op: cycle counter after every layer, first 8 images x 32 slots
   MegaOp ops[kMegaMaxOps];
 };
@@ -64,34 +66,63 @@ struct MegaArgs {
 //   every MFMA (600-2000 cycles per K step, 0.21-0.29 ms per batch); asm loads into registers are not usable, the register
 //   allocator copies a ring register (loop phi) while its load is still in flight.
 struct MegaStream {
-  v4i_t rs;
-  uint32_t arow;                            // byte offset of this lane's 16 bytes of step 0
+  v4i_t rs, rsb;                            // weights, bias
+  uint32_t arow;                            // byte offset of this lane's 16 bytes of step 0 (a step is 1 KiB further)
+  uint32_t boff;                            // byte offset of this lane's bias word (lanes 0..15; the others out of range)
   int nsteps;                               // 0: no such item
 };
 constexpr uint32_t kMegaOob = 0x80000000u;  // offset past any weight tensor: the load returns zeros
 
-__device__ __forceinline__ void mega_load(uint32_t slot_addr, const v4i_t rs, uint32_t off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(slot_addr), "v"(off), "s"(rs) : "memory", "m0");
+// Fill of ring slot U.  M0 (the LDS base of an LDS-DMA) is the SAME value for every fill of a wave; the slot is chosen by
+// the instruction's 12-bit offset, which the hardware adds to the LDS address AND to the memory address - the descriptors
+// therefore start kMegaBack bytes early and the lane offset carries kMegaBack - 1024 U.  Why: with M0 rewritten per fill,
+// fills issued a few instructions apart (the ring's refill-only visits) landed in the wrong slot once the caches were warm
+// - 20-40 % of the images of every launch after the first; 16 idle cycles after each fill hid it, 4 did not, stricter
+// vmcnt waits did not.  A queued LDS-DMA evidently samples M0 after later SALU writes can reach it; nothing may depend on
+// how long that window is, so M0 never changes while fills are in flight.
+constexpr uint32_t kMegaBack = (kMegaPf - 1) * 1024;
+template <int U>
+__device__ __forceinline__ void mega_load(uint32_t ring, const v4i_t rs, uint32_t off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%3 lds"
+               :: "s"(ring), "v"(off + (kMegaBack - U * 1024)), "s"(rs), "n"(U * 1024) : "memory", "m0");
+}
+__device__ __forceinline__ v4i_t mega_srd(const void* p, uint32_t bytes) {
+  return make_srd(static_cast<const char*>(p) - kMegaBack, bytes + kMegaBack);
+}
+// an item's 16 biases: one dword LDS-DMA (lane l < 16 lands at slot + 4 l), an extra load in the stream - extra loads only
+// make the counted waits stricter, never wrong (loads complete in order).  Its slot lies outside the ring's M0 window: the
+// statement waits out the fills' sampling window on both sides of its own M0 (once per item, next to an epilogue).
+__device__ __forceinline__ void mega_load_bias(uint32_t slot_addr, uint32_t ring, const v4i_t rs, uint32_t off) {
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_nop 15\n\ts_nop 15\n\ts_mov_b32 m0, %3"
+               :: "s"(slot_addr), "v"(off), "s"(rs), "s"(ring) : "memory", "m0");
 }
 __device__ __forceinline__ void mega_wait_slot() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf - 1) : "memory"); }
 __device__ __forceinline__ void mega_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+__device__ __forceinline__ uint32_t mega_arow(int n_t, int nsteps, int lane) { return (uint32_t)((n_t * nsteps * 64 + lane) * 16); }
+__device__ __forceinline__ uint32_t mega_boff(int n_t, int lane) { return lane < 16 ? (uint32_t)((n_t * 16 + lane) * 4) : kMegaOob; }
+
 __device__ __forceinline__ MegaStream mega_first_item(const MegaOp& nx, bool has, int wave, int lane) {
-  const int frow = lane & 15, kq = lane >> 4;
   const int mt = (nx.hout * nx.wout + 15) / 16, nt = nx.cout / 16, ng = (mt + 3) / 4;
   MegaStream st;
-  st.rs = make_srd(nx.w, (uint32_t)nx.wbytes);
+  st.rs = mega_srd(nx.w, (uint32_t)nx.wbytes);
+  st.rsb = make_srd(nx.bias, (uint32_t)(nx.cout * 4));
   const int n_t = wave / ng;
-  st.arow = (uint32_t)(((n_t * 16 + frow) * nx.kpad + 8 * kq) * 2);
-  st.nsteps = (has && nx.kind == 1 && wave < nt * ng) ? nx.kpad / 32 : 0;
+  const bool live = has && nx.kind == 1 && wave < nt * ng;
+  st.nsteps = live ? nx.kpad / 32 : 0;
+  st.arow = mega_arow(n_t, nx.kpad / 32, lane);
+  st.boff = live ? mega_boff(n_t, lane) : kMegaOob;
   return st;
 }
 
-// (re)start the ring
-__device__ __forceinline__ void mega_prefetch(const MegaStream& st, uint32_t ring) {
-#pragma unroll
-  for (int u = 0; u < kMegaPf; ++u) mega_load(ring + u * 1024, st.rs, (u < st.nsteps) ? st.arow + (uint32_t)(u * 64) : kMegaOob);
+// (re)start the stream: bias of the wave's first item of the next layer, then its first kMegaPf steps
+__device__ __forceinline__ void mega_prefetch(const MegaStream& st, uint32_t ring, uint32_t bslot) {
+  mega_load_bias(bslot, ring, st.rsb, st.boff);
+  mega_load<0>(ring, st.rs, (0 < st.nsteps) ? st.arow : kMegaOob);
+  mega_load<1>(ring, st.rs, (1 < st.nsteps) ? st.arow + 1024u : kMegaOob);
+  mega_load<2>(ring, st.rs, (2 < st.nsteps) ? st.arow + 2048u : kMegaOob);
+  mega_load<3>(ring, st.rs, (3 < st.nsteps) ? st.arow + 3072u : kMegaOob);
+  static_assert(kMegaPf == 4, "one M0 reaches 4 KiB of LDS");
 }
 
 __device__ __forceinline__ void mega_stem(const MegaArgs& a, const MegaOp& op, unsigned char* smem, int img, int wave, int lane) {
@@ -184,31 +215,40 @@ __device__ __forceinline__ int mega_toff(const MegaItem& it, int ks, int kq) {
 // One turn of the ring: slots 0..NU-1 hold K steps k0..k0+NU-1 of the item and are consumed; every slot is then refilled
 // (the ring's rotation stays uniform, which is what makes the hand-counted vmcnt exact).  Branch-free: NPT pixel tiles per
 // weight fragment, the activation fragments of the next step are read before the MFMAs of this one.
+template <int NPT, int NU, int U>
+__device__ __forceinline__ void mega_visit(const MegaItem& it, const unsigned char* smem, const int (&base)[4], int kq, int k0,
+                                           uint32_t ring, int lane, f32x4 (&acc)[4], uint4 (&bf)[4]) {
+  const int ks = k0 + U;
+  mega_wait_slot();
+  if (U < NU) {
+    const uint4 af = *reinterpret_cast<const uint4*>(smem + ring + U * 1024 + lane * 16);
+    const int tn = mega_toff(it, ks + 1, kq);
+    uint4 bn[4];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) bn[j] = *reinterpret_cast<const uint4*>(smem + base[j] + tn);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&af), *reinterpret_cast<const f16x8*>(&bf[j]), acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) bf[j] = bn[j];
+  }
+  // slot U is free: step ks + kMegaPf of this item, or - past its end - step U of the wave's next item
+  const int t = ks + kMegaPf;
+  const bool cur = t < it.nsteps;
+  const uint32_t off = cur ? it.arow + (uint32_t)(t * 1024) : ((U < it.nsteps_n) ? it.arow_n + (uint32_t)(U * 1024) : kMegaOob);
+  mega_load<U>(ring, cur ? it.rsw : it.rs_n, off);
+}
+
+// One turn of the ring: slots 0..NU-1 hold K steps k0..k0+NU-1 of the item and are consumed; every slot is then refilled
+// (the ring's rotation stays uniform, which is what makes the hand-counted vmcnt exact).  Branch-free: NPT pixel tiles per
+// weight fragment, the activation fragments of the next step are read before the MFMAs of this one.
 template <int NPT, int NU>
 __device__ __forceinline__ void mega_block(const MegaItem& it, const unsigned char* smem, const int (&base)[4], int kq, int k0,
                                            uint32_t ring, int lane, f32x4 (&acc)[4], uint4 (&bf)[4]) {
-#pragma unroll
-  for (int u = 0; u < kMegaPf; ++u) {
-    const int ks = k0 + u;
-    mega_wait_slot();
-    if (u < NU) {
-      const uint4 af = *reinterpret_cast<const uint4*>(smem + ring + u * 1024 + lane * 16);
-      const int tn = mega_toff(it, ks + 1, kq);
-      uint4 bn[4];
-#pragma unroll
-      for (int j = 0; j < NPT; ++j) bn[j] = *reinterpret_cast<const uint4*>(smem + base[j] + tn);
-#pragma unroll
-      for (int j = 0; j < NPT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&af), *reinterpret_cast<const f16x8*>(&bf[j]), acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NPT; ++j) bf[j] = bn[j];
-    }
-    // slot u is free: step ks + kMegaPf of this item, or - past its end - step u of the wave's next item
-    const int t = ks + kMegaPf;
-    const bool cur = t < it.nsteps;
-    const uint32_t off = cur ? it.arow + (uint32_t)(t * 64) : ((u < it.nsteps_n) ? it.arow_n + (uint32_t)(u * 64) : kMegaOob);
-    mega_load(ring + u * 1024, cur ? it.rsw : it.rs_n, off);
-  }
+  mega_visit<NPT, NU, 0>(it, smem, base, kq, k0, ring, lane, acc, bf);
+  mega_visit<NPT, NU, 1>(it, smem, base, kq, k0, ring, lane, acc, bf);
+  mega_visit<NPT, NU, 2>(it, smem, base, kq, k0, ring, lane, acc, bf);
+  mega_visit<NPT, NU, 3>(it, smem, base, kq, k0, ring, lane, acc, bf);
 }
 
 template <int NPT>
@@ -220,44 +260,38 @@ __device__ __forceinline__ void mega_kloop(const MegaItem& it, const unsigned ch
   for (int j = 0; j < NPT; ++j) bf[j] = *reinterpret_cast<const uint4*>(smem + base[j] + t0);
   int k0 = 0;
   for (; k0 + kMegaPf <= it.nsteps; k0 += kMegaPf) mega_block<NPT, kMegaPf>(it, smem, base, kq, k0, ring, lane, acc, bf);
-  switch (it.nsteps - k0) {                                            // K is padded to 64: the step count is even
-    case 2: mega_block<NPT, 2>(it, smem, base, kq, k0, ring, lane, acc, bf); break;
-    case 4: mega_block<NPT, 4>(it, smem, base, kq, k0, ring, lane, acc, bf); break;
-    case 6: mega_block<NPT, 6>(it, smem, base, kq, k0, ring, lane, acc, bf); break;
-    default: break;
-  }
+  if (it.nsteps - k0 == 2) mega_block<NPT, 2>(it, smem, base, kq, k0, ring, lane, acc, bf);   // K is padded to 64: the step count is even
 }
 
 __device__ __forceinline__ void mega_conv(const MegaOp& op, const MegaStream& nx, unsigned char* smem, int wave, int lane,
-                                          uint32_t ring, unsigned long long* fine) {
-  typedef const float __attribute__((address_space(4))) cfloat_t;     // constant address space: uniform loads go through SMEM
+                                          uint32_t ring, uint32_t bring, int& bsel, unsigned long long* fine) {
   const int frow = lane & 15, kq = lane >> 4;
   const int M = op.hout * op.wout, mt = (M + 15) / 16, nt = op.cout / 16, ng = (mt + 3) / 4;
   const int nitems = nt * ng;
   const int pad = op.ksize == 3 ? 1 : 0;
   if (wave >= nitems) {                                                // idle in this layer: fetch for the next one
-    mega_prefetch(nx, ring);
+    bsel ^= 1;
+    mega_prefetch(nx, ring, bring + bsel * 256);
     return;
   }
+  const v4i_t rsb = make_srd(op.bias, (uint32_t)(op.cout * 4));
   MegaItem it;
-  it.rsw = make_srd(op.w, (uint32_t)op.wbytes);
+  it.rsw = mega_srd(op.w, (uint32_t)op.wbytes);
   it.nsteps = op.kpad / 32;
   it.ksize = op.ksize; it.lg_cpt = op.lg_cpt; it.cptm = (1 << op.lg_cpt) - 1; it.cpt1 = op.cin / 8 - 1;
   it.src_wp = op.src_wp; it.src_ps = op.src_ps;
   for (int item = wave; item < nitems; item += kMegaWaves) {
     const int n_t = item / ng, g = item - n_t * ng;
     const int n = n_t * 16 + kq * 4;                                   // lane's 4 output channels (C/D map of the 16x16 MFMA)
-    cfloat_t* bp = (cfloat_t*)(unsigned long long)(op.bias + n_t * 16);
-    float bs[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) bs[i] = bp[i];
-    // what the ring fetches once this item's steps are all in flight
+    // what the stream fetches once this item's steps are all in flight; the next item's bias goes out now (slot bsel holds
+    // this item's, fetched an item ago)
     const bool more = item + kMegaWaves < nitems;
     const int n_tn = (item + kMegaWaves) / ng;
-    it.arow = (uint32_t)(((n_t * 16 + frow) * op.kpad + 8 * kq) * 2);
-    it.arow_n = more ? (uint32_t)(((n_tn * 16 + frow) * op.kpad + 8 * kq) * 2) : nx.arow;
+    it.arow = mega_arow(n_t, it.nsteps, lane);
+    it.arow_n = more ? mega_arow(n_tn, it.nsteps, lane) : nx.arow;
     it.nsteps_n = more ? it.nsteps : nx.nsteps;
     it.rs_n = more ? it.rsw : nx.rs;
+    mega_load_bias(bring + (bsel ^ 1) * 256, ring, more ? rsb : nx.rsb, more ? mega_boff(n_tn, lane) : nx.boff);
     int base[4], pdst[4];
     bool pv[4];
 #pragma unroll
@@ -278,9 +312,10 @@ __device__ __forceinline__ void mega_conv(const MegaOp& op, const MegaStream& nx
     else mega_kloop<4>(it, smem, base, kq, ring, lane, acc);                   // 2 or 3 tiles: the others recompute pixel 0, never stored
     // epilogue: lane holds channels n..n+3 of pixel p
     if (fine && item == wave && lane == 0) fine[2] = __builtin_readcyclecounter();
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = kq == 0 ? bs[r] : kq == 1 ? bs[4 + r] : kq == 2 ? bs[8 + r] : bs[12 + r];
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf) : "memory");      // the bias is older than the ring's fills in flight
+    const float4 b4 = *reinterpret_cast<const float4*>(smem + bring + bsel * 256 + kq * 16);
+    bsel ^= 1;
+    const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < npt && pv[j]) {
@@ -305,6 +340,16 @@ __device__ __forceinline__ void mega_conv(const MegaOp& op, const MegaStream& nx
   }
 }
 
+// [cout][kpad] f16 -> fragment order: chunk (n_t, ks, lane) = the 16 bytes lane (kq = lane / 16, row = lane % 16) feeds the MFMA
+__global__ void mega_repack_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int cout, int kpad) {
+  const int nsteps = kpad / 32, total = (cout / 16) * nsteps * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, ks = (i >> 6) % nsteps, n_t = (i >> 6) / nsteps;
+    const uint4 v = *reinterpret_cast<const uint4*>(w + (long)(n_t * 16 + (lane & 15)) * kpad + ks * 32 + (lane >> 4) * 8);
+    *reinterpret_cast<uint4*>(out + (long)i * 8) = v;
+  }
+}
+
 // workgroup barrier for LDS traffic only: no vmcnt wait, the weight ring stays in flight across it
 __device__ __forceinline__ void mega_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -318,10 +363,13 @@ __global__ __launch_bounds__(kMegaWaves * 64) void cls_mega_kernel(const MegaArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (a.stamps && img < 8 && tid == 0) a.stamps[img * 32 + 31] = __builtin_readcyclecounter();
   const uint32_t ring = (uint32_t)(a.ring_off + wave * (kMegaPf * 1024));   // this wave's weight ring
+  const uint32_t bring = (uint32_t)(a.bias_off + wave * 512);              // and its two bias slots
+  int bsel = 0;
   MegaOp op = a.ops[0];
+  MegaOp nxo = a.ops[a.nops > 1 ? 1 : 0];
   for (int oi = 0; oi < a.nops; ++oi) {
     const bool has = oi + 1 < a.nops;
-    const MegaOp nxo = a.ops[has ? oi + 1 : oi];                         // descriptor of the next layer, fetched a layer ahead
+    const MegaOp nno = a.ops[oi + 2 < a.nops ? oi + 2 : oi];               // layer descriptors are fetched two layers ahead
     const MegaStream nx = mega_first_item(nxo, has, wave, lane);
     if (op.zero_rows > 0) {
       // a buffer a 3x3 conv will read starts its life: clear its halo ring (disjoint from what this layer writes)
@@ -336,16 +384,17 @@ __global__ __launch_bounds__(kMegaWaves * 64) void cls_mega_kernel(const MegaArg
         *reinterpret_cast<uint4*>(smem + op.zero_off + (row * wp + col) * op.dst_ps + c * 16) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    if (op.kind == 0) { mega_stem(a, op, smem, img, wave, lane); mega_prefetch(nx, ring); }
+    if (op.kind == 0) { mega_stem(a, op, smem, img, wave, lane); mega_prefetch(nx, ring, bring); }
     else {
       unsigned long long* fine = (a.stamps && img == 0 && wave == 0) ? a.stamps + 256 + oi * 4 : nullptr;
       if (fine && lane == 0) fine[0] = __builtin_readcyclecounter();
-      mega_conv(op, nx, smem, wave, lane, ring, fine);
+      mega_conv(op, nx, smem, wave, lane, ring, bring, bsel, fine);
       if (fine && lane == 0) fine[3] = __builtin_readcyclecounter();
     }
     mega_barrier();
     if (a.stamps && img < 8 && tid == 0) a.stamps[img * 32 + oi] = __builtin_readcyclecounter();
     op = nxo;
+    nxo = nno;
   }
   mega_drain();
   // ---- Classify tail (arithmetic order of cls_head_kernel): avg-pool -> Linear -> softmax

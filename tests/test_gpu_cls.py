@@ -152,3 +152,23 @@ def test_one_launch_classifier_is_bit_identical_to_the_layered_path(rank_bundles
     assert torch.equal(l0, l1) and torch.equal(p0, p1)
     if B >= 67:
         assert int((p1[:67].argmax(1).cpu().numpy() == rank_valid["labels"]).sum()) == 63
+
+
+@pytest.mark.gpu
+def test_one_launch_classifier_replays_bit_identically_with_warm_caches(rank_bundles):
+    """The weight rings are LDS-DMA fills with hand-counted waits; a fill that lands in the wrong slot shows up only once
+    the caches are warm (second launch on), on a fraction of the images.  Replay the same batch and demand the same bits
+    as the layered path every time (csrc/cls_mega.h, note at mega_load)."""
+    from manual_yolo_amd.engine import engine_from_weights
+    sd, meta = rank_bundles["best"]
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    g = torch.Generator().manual_seed(7)
+    for B, reps in ((256, 10), (1, 24), (777, 3)):
+        x = torch.randint(0, 256, (B, 64, 64, 3), dtype=torch.uint8, generator=g).cuda()
+        eng.set_option("cls_mega", 1)
+        assert eng.classify_launches(64, 64)[0] == 1
+        outs = [eng.classify(x)[0].clone() for _ in range(reps)]
+        eng.set_option("cls_mega", 0)
+        ref = eng.classify(x)[0].clone()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, ref), f"batch {B}, replay {i}: {int(((o - ref).abs().max(1).values > 0).sum())} images differ"

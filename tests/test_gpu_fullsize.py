@@ -74,6 +74,19 @@ def test_fullsize_determinism_independence_and_nms_invariants(model, dtype, B, H
         assert np.array_equal(d1[b, :n].cpu().numpy(), outs[b])
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_fullsize_head_output_replays_bit_identically(model, dtype):
+    """Every conv kernel here stages its tiles by LDS-DMA behind hand-counted waits, each fill with its own M0; a fill
+    that lands in the wrong place would show as launches that differ once the caches are warm (seen in the classifier's
+    weight rings, csrc/cls_mega.h).  Eight replays of one batch must give the same bits."""
+    eng = model[dtype]
+    B = 64 if dtype == "f16" else 16
+    frames = torch.from_numpy(synth_frames(B, 640, 640, seed=11, kind="noise")).cuda()
+    ref = eng.head_raw(frames).clone()
+    for i in range(8):
+        assert torch.equal(eng.head_raw(frames), ref), f"replay {i} differs"
+
+
 def test_fullsize_kernel_generations_agree_bit_exactly_in_f32(model):
     """Exact mode, batch 64 at 640x640: the persistent ring kernels (256x192 tile, interleaved DMA issue, 2-D-tile kernel)
     and the first LDS-DMA kernel accumulate in the same order, so their head outputs must be bit-identical - a
