@@ -192,7 +192,11 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * (1: detect/classify calls are captured into a hipGraph and replayed while shape, thresholds,
  * stream and pointers stay the same; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
  * "h2_min_util" percent (70) of the map; "h2_warm" = 1 selects its persistent form), "cls_mega" (1 default: an f16 classifier whose activations fit LDS runs as ONE launch, cls_mega.h; 0: one launch per
- * layer; bit-identical results), "cls_streams" (1 default:
+ * layer; bit-identical results), "head_lanes" (1 default: detect runs the Detect head's independent conv chains - per level
+ * the first conv and the box / class branches behind it - on internal side streams, forked and joined by events around
+ * the caller's stream; 0: everything in order on the caller's stream; same kernels, same results), "batch_split" (0 default;
+ * K > 1: a batch that fits one pass runs as K part batches on K streams when the workspace holds K part plans - measured
+ * +0.8..1.4 % on configuration 1, left off), "cls_streams" (1 default:
  * > 1 makes miyolo_classify fork the batch over that many internal streams, joined by events - measured slower), and the
  * timing-experiment switches "ablate" / "dbg_op" of the non-shipped builds.  Setting any option
  * drops the captured graphs. */

@@ -182,18 +182,27 @@ class _Builder:
         return self.conv(Value([View(ybuf, 0, 4 * c_)], x.down), prefix + ".cv2", c2, 1, 1)
 
     # [3P] ultralytics.nn.modules.head.Detect (legacy=True: plain Conv cls branch)
-    def detect(self, xs: Sequence[Value], prefix: str, nc: int):
+    def detect(self, xs: Sequence[Value], prefix: str, nc: int, fuse_first: bool = False):
+        """``fuse_first``: cv2[l][0] and cv3[l][0] are both conv3x3 + BN + SiLU over the same level input; run them as ONE
+        conv of c2 + c3 output channels (one launch, the input read once, 4x the output tiles on P5 where 64 channels
+        alone cannot fill the chip) whose output the two second convs read as channel slices.  Same arithmetic per
+        output channel, so results are unchanged bit for bit."""
         ch = [x.channels for x in xs]
         c2 = max(16, ch[0] // 4, REG_MAX * 4)
         c3 = max(ch[0], min(nc, 100))
         raws, strides = [], []
         for l, x in enumerate(xs):
             raw = self.buf(4 * REG_MAX + nc, x.down, 0)   # fp32 [.., 64 box | nc cls]
-            b = self.conv(x, f"{prefix}.cv2.{l}.0", c2, 3, 1)
+            if fuse_first:
+                f = self.conv(x, f"{prefix}.cv2.{l}.0|{prefix}.cv3.{l}.0", c2 + c3, 3, 1)
+                fb = f.views[0].buf
+                b = Value([View(fb, 0, c2)], x.down)
+            else:
+                b = self.conv(x, f"{prefix}.cv2.{l}.0", c2, 3, 1)
             b = self.conv(b, f"{prefix}.cv2.{l}.1", c2, 3, 1)
             self.conv(b, f"{prefix}.cv2.{l}.2", 4 * REG_MAX, 1, 1, act=0, fused_bn=False,
                       dst=View(raw, 0, 4 * REG_MAX))
-            c = self.conv(x, f"{prefix}.cv3.{l}.0", c3, 3, 1)
+            c = Value([View(fb, c2, c3)], x.down) if fuse_first else self.conv(x, f"{prefix}.cv3.{l}.0", c3, 3, 1)
             c = self.conv(c, f"{prefix}.cv3.{l}.1", c3, 3, 1)
             self.conv(c, f"{prefix}.cv3.{l}.2", nc, 1, 1, act=0, fused_bn=False,
                       dst=View(raw, 4 * REG_MAX, nc))
@@ -214,7 +223,7 @@ class _Builder:
 
 
 def build_program(task: str, nc: int, scale: str, spec: Optional[dict] = None,
-                  nc_quirk: bool = True) -> Program:
+                  nc_quirk: bool = True, fuse_head: bool = False) -> Program:
     """[3P] parse_model restated: see module docstring.  ``nc_quirk``: upstream only scales a
     layer's width ``if c2 != nc``; a yolov8m trained by Ultralytics with nc=64 (reference
     ``roadmap1.v3i.yolov8/data.yaml:5``) therefore has a 64-wide stem.  ``False`` gives the
@@ -250,7 +259,7 @@ def build_program(task: str, nc: int, scale: str, spec: Optional[dict] = None,
             assert len({v.down for v in xin}) == 1, "Concat of different resolutions"
             x = Value([vw for v in xin for vw in v.views], xin[0].down)
         elif m == "Detect":
-            b.detect(xin, prefix, nc)
+            b.detect(xin, prefix, nc, fuse_head)
             x = None
         elif m == "Classify":
             b.classify(xin, prefix, nc)

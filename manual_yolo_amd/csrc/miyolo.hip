@@ -84,6 +84,15 @@ struct miyolo_engine {
                             // 1.12 M img/s, 2: 0.85 M, 4: 0.40 M, 8: 0.29 M (captured in a hipGraph: 0.88 / 0.84 / 0.57 / 0.42 M) - the
                             // front end takes ~8 us per dispatch whether or not the chains are independent; only fewer launches help
   std::vector<hipStream_t> lanes;
+  int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
+  std::vector<hipStream_t> split_streams;
+  std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
+  int head_lanes = 1;       // detect: the Detect head's independent conv chains on side streams (build_lanes)
+  std::vector<int> op_lane;                 // lane of each op (0 = the caller's stream)
+  std::vector<std::vector<int>> op_waits;   // ops on OTHER lanes op i must wait for (latest per lane)
+  std::vector<char> op_signal;              // op i has a consumer on another lane: record its event
+  std::vector<hipEvent_t> op_ev;
+  int n_lanes = 1;
   std::vector<hipEvent_t> lane_ev;   // [0] fork, [1 + i] join of lane i
   uint32_t cls_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // `classes=` filter of the NMS prefilter (miyolo_set_classes)
   int use_cls_mask = 0;
@@ -514,21 +523,97 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   return impl * 1000 + op.ksize * 100 + c.wc * 10 + c.tc;   // e.g. 3323 = conv_dmap_kernel<T,3,2,3>
 }
 
+// Which ops may run beside each other.  Dependencies are read off the views (RAW, WAR, WAW on overlapping channel ranges of
+// one buffer).  Ops whose results only the decode op consumes - the Detect head: per level one (fused) first conv and two
+// conv chains - leave the caller's stream: each chain gets a side stream, forked by an event behind its producer and
+// joined in front of the decode.  The P3 chains then run beside the P4 / P5 neck, and the small P5 kernels (20 x 20 maps,
+// too few tiles for 256 CUs) beside each other.  Same kernels, same arguments: results cannot change.
+void build_lanes(miyolo_engine* h) {
+  const int n = (int)h->ops.size();
+  h->op_lane.assign(n, 0); h->op_waits.assign(n, {}); h->op_signal.assign(n, 0); h->n_lanes = 1;
+  int D = -1;
+  for (int i = 0; i < n; ++i) if (h->ops[i].kind == MIYOLO_OP_DECODE) D = i;
+  if (h->desc.task != 0 || D < 0) return;
+  auto overlap = [](const miyolo_view& a, const miyolo_view& b) {
+    return a.buf > 0 && a.buf == b.buf && a.ch_off < b.ch_off + b.ch_cnt && b.ch_off < a.ch_off + a.ch_cnt;
+  };
+  auto reads = [&](const miyolo_op& op, std::vector<miyolo_view>* v) {
+    v->clear();
+    const int ns = op.kind == MIYOLO_OP_CONV ? op.n_src : op.kind == MIYOLO_OP_DECODE ? 3 : 1;
+    for (int k = 0; k < ns; ++k) v->push_back(op.src[k]);
+    if (op.kind == MIYOLO_OP_CONV && op.res.buf >= 0) v->push_back(op.res);
+  };
+  std::vector<std::vector<int>> raw(n), any(n);          // predecessors: true data flow / every ordering constraint
+  std::vector<miyolo_view> ri, rj;
+  for (int j = 0; j < n; ++j) {
+    reads(h->ops[j], &rj);
+    for (int i = 0; i < j; ++i) {
+      reads(h->ops[i], &ri);
+      const bool wi = h->ops[i].kind != MIYOLO_OP_DECODE, wj = h->ops[j].kind != MIYOLO_OP_DECODE;   // decode writes y, not a buffer
+      bool r = false, o = false;
+      for (const auto& v : rj) if (wi && overlap(v, h->ops[i].dst)) r = true;
+      for (const auto& v : ri) if (wj && overlap(v, h->ops[j].dst)) o = true;
+      if (wi && wj && overlap(h->ops[i].dst, h->ops[j].dst)) o = true;
+      if (r) raw[j].push_back(i);
+      if (r || o) any[j].push_back(i);
+    }
+  }
+  std::vector<char> head(n, 0);
+  for (int i = D - 1; i >= 0; --i) {
+    bool used = false, only_head = true;
+    for (int j = i + 1; j <= D; ++j)
+      for (int pi : raw[j]) if (pi == i) { used = true; if (j != D && !head[j]) only_head = false; }
+    head[i] = used && only_head;
+  }
+  std::vector<char> handed(n, 0);
+  for (int i = 0; i < D; ++i) {
+    if (!head[i]) continue;
+    int lane = 0;
+    for (int pi : raw[i]) if (head[pi] && !handed[pi]) { lane = h->op_lane[pi]; handed[pi] = 1; break; }
+    if (lane == 0) lane = h->n_lanes++;
+    h->op_lane[i] = lane;
+  }
+  for (int j = 0; j < n; ++j) {
+    std::vector<int> latest(h->n_lanes, -1);
+    for (int pi : any[j]) if (h->op_lane[pi] != h->op_lane[j]) latest[h->op_lane[pi]] = std::max(latest[h->op_lane[pi]], pi);
+    for (int l = 0; l < h->n_lanes; ++l) if (latest[l] >= 0) { h->op_waits[j].push_back(latest[l]); h->op_signal[latest[l]] = 1; }
+  }
+}
+
 int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
             float* cls_logits, float* cls_probs, hipStream_t s) {
+  const bool lanes = h->head_lanes && !h->profile && h->n_lanes > 1 && first == 0 && last == (int)h->ops.size();
+  if (lanes) {
+    while ((int)h->lanes.size() < h->n_lanes - 1) {
+      hipStream_t st;
+      HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      h->lanes.push_back(st);
+    }
+    while (h->op_ev.size() < h->ops.size()) {
+      hipEvent_t ev;
+      HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->op_ev.push_back(ev);
+    }
+  }
   for (int i = first; i < last; ++i) {
     miyolo_engine::ProfRec rec{i, 0, nullptr, nullptr};
+    hipStream_t si = s;
+    if (lanes) {
+      if (h->op_lane[i] > 0) si = h->lanes[h->op_lane[i] - 1];
+      for (int pi : h->op_waits[i]) HIP_TRY(h, hipStreamWaitEvent(si, h->op_ev[pi], 0));
+    }
     if (h->profile) {
       rec.cfg = conv_cfg_id(h, h->ops[i], p);
       HIP_TRY(h, hipEventCreate(&rec.e0));
       HIP_TRY(h, hipEventCreate(&rec.e1));
       HIP_TRY(h, hipEventRecord(rec.e0, s));
     }
-    const int rc = (h->desc.dtype == MIYOLO_F8) ? run_op<fp8_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s)
+    const int rc = (h->desc.dtype == MIYOLO_F8) ? run_op<fp8_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
                    : (h->desc.dtype == MIYOLO_F16)
-                       ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s)
-                       : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, s);
+                       ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
+                       : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si);
     if (rc) return rc;
+    if (lanes && h->op_signal[i]) HIP_TRY(h, hipEventRecord(h->op_ev[i], si));
     if (h->profile) {
       HIP_TRY(h, hipEventRecord(rec.e1, s));
       h->prof.push_back(rec);
@@ -778,6 +863,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
       return fail(nullptr, MIYOLO_ERR_ARG, "op references a missing weight");
     }
   }
+  build_lanes(h);
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = set_conv_attrs_ks<float, 1>();
   if (e == hipSuccess) e = set_conv_attrs_ks<float, 3>();
@@ -830,6 +916,9 @@ void miyolo_destroy(miyolo_handle h) {
   drop_graphs(h);
   for (hipStream_t st : h->lanes) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : h->lane_ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : h->op_ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st : h->split_streams) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : h->split_ev) (void)hipEventDestroy(ev);
   if (h->dbg) (void)hipFree(h->dbg);
   if (h->mega_wbuf) (void)hipFree(h->mega_wbuf);
   delete h;
@@ -864,6 +953,8 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
   if (!strcmp(key, "cls_mega")) { h->cls_mega = value; return 0; }
+  if (!strcmp(key, "head_lanes")) { h->head_lanes = value; return 0; }
+  if (!strcmp(key, "batch_split")) { h->batch_split = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }
   if (!strcmp(key, "h2_min_util")) { h->h2_min_util = value; return 0; }
@@ -931,6 +1022,40 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
   struct { int entry, B, H, W, agnostic, max_det; float conf, iou; const void* in; const void* scale; void* d; void* c; void* a; void* ws; hipStream_t s; }
       key = {1, B, H, W, agnostic, max_det, conf, iou, in, scale, out_dets, out_counts, out_anchor, workspace, s};
   return with_graph(h, s, &key, sizeof(key), [&]() -> int {
+    const int K = h->batch_split;
+    if (K > 1 && B == p.B && B % K == 0 && !h->profile) {
+      Plan p2;
+      make_plan(h, B / K, H, W, &p2);
+      const size_t part = align_up(p2.total, 256);
+      if ((size_t)K * part <= workspace_bytes) {
+        while ((int)h->split_streams.size() < K - 1) {
+          hipStream_t st;
+          HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+          h->split_streams.push_back(st);
+        }
+        while ((int)h->split_ev.size() < K) {
+          hipEvent_t ev;
+          HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          h->split_ev.push_back(ev);
+        }
+        HIP_TRY(h, hipEventRecord(h->split_ev[0], s));
+        for (int k = 0; k < K; ++k) {
+          hipStream_t sk = k ? h->split_streams[k - 1] : s;
+          if (k) HIP_TRY(h, hipStreamWaitEvent(sk, h->split_ev[0], 0));
+          unsigned char* wk = static_cast<unsigned char*>(workspace) + k * part;
+          const int b0 = k * (B / K);
+          if (int rc = run_ops(h, 0, (int)h->ops.size(), p2, in + (size_t)b0 * H * W * 3, wk, nullptr, nullptr, sk)) return rc;
+          if (int rc = run_nms(h, p2, reinterpret_cast<const float*>(wk + p2.y_off), p2.B, p2.A, conf, iou, agnostic, max_det,
+                               scale ? scale + (size_t)b0 * 5 : nullptr, out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
+                               out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, wk, sk)) return rc;
+          if (k) {
+            HIP_TRY(h, hipEventRecord(h->split_ev[k], sk));
+            HIP_TRY(h, hipStreamWaitEvent(s, h->split_ev[k], 0));
+          }
+        }
+        return 0;
+      }
+    }
     for (int b0 = 0; b0 < B; b0 += p.B) {
       Plan pc = p;
       pc.B = std::min(p.B, B - b0);

@@ -421,11 +421,13 @@ class Engine:
 
 def engine_from_weights(sd: Dict[str, torch.Tensor], meta: dict, dtype: str = "f16", device: Optional[int] = None,
                         bgr_input: bool = True, calib_frames: Optional[torch.Tensor] = None, quant=None,
-                        gain_fix: bool = True) -> Engine:
+                        gain_fix: bool = True, fuse_head: bool = True) -> Engine:
     """dtype "f8" (detect only): static e4m3 quantisation, calibrated on `calib_frames` (uint8 [N,H,W,3]; default: eight
     seeded synthetic frames at the model's image size) through the f16 engine, followed by the per-op gain correction
     of quant.gain_correction - see quant.py."""
-    prog = build_program(meta["task"], meta["nc"], meta["scale"], meta.get("spec"), meta.get("nc_quirk", True))
+    # Detect's two first convs per level run as one (f16 / f32; the fp8 build keeps them apart: one activation scale per op)
+    prog = build_program(meta["task"], meta["nc"], meta["scale"], meta.get("spec"), meta.get("nc_quirk", True),
+                         fuse_head=(dtype != "f8") and fuse_head)
     if dtype != "f8":
         return Engine(prog, sd, meta["bn_eps"], dtype, device, bgr_input, quant)
     from .quant import calibrate, gain_correction

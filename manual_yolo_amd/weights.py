@@ -19,7 +19,11 @@ TORCH_DTYPE = {"f32": torch.float32, "f16": torch.float16}
 
 
 def fold_conv(sd: Dict[str, torch.Tensor], r: WeightRecipe, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(weight [cout,cin,k,k] fp32, bias [cout] fp32) of one conv with its BN folded in."""
+    """(weight [cout,cin,k,k] fp32, bias [cout] fp32) of one conv with its BN folded in.  A prefix "a|b" names two convs
+    over the same input run as one (arch.py, Detect's first convs): their folded weights concatenated along cout."""
+    if "|" in r.prefix:
+        parts = [fold_conv(sd, WeightRecipe(r.kind, p, r.fused_bn, r.seg_channels), eps) for p in r.prefix.split("|")]
+        return torch.cat([w for w, _ in parts], 0), torch.cat([b for _, b in parts], 0)
     if r.fused_bn:
         w = sd[r.prefix + ".conv.weight"].float()
         g = sd[r.prefix + ".bn.weight"].float()

@@ -342,3 +342,33 @@ def test_nms_on_real_label_layouts_bit_exact(small, real_frames):
             assert n == len(idxs[b]) and n > 5
             assert np.array_equal(anchor[b, :n].cpu().numpy(), idxs[b])
             assert np.array_equal(dets[b, :n].cpu().numpy(), outs[b])
+
+
+@pytest.mark.parametrize("scale,dtype", [("n", "f32"), ("m", "f16"), ("m", "f32")])
+def test_fused_detect_first_convs_change_no_bit(scale, dtype):
+    """The engine runs Detect's cv2[l][0] and cv3[l][0] (reference: ultralytics Detect.forward, one 3x3 Conv each over the
+    same level input) as ONE conv of c2 + c3 channels.  Per output channel the arithmetic is the same, so the head output
+    must equal the unfused program's bit for bit."""
+    sd, meta = synth_state_dict("detect", NC, scale, 0, nc_quirk=False), synth_meta("detect", NC, scale, False)
+    fused = engine_from_weights(sd, meta, dtype, 0, bgr_input=False)
+    plain = engine_from_weights(sd, meta, dtype, 0, bgr_input=False, fuse_head=False)
+    assert len(plain.prog.ops) - len(fused.prog.ops) == 3
+    frames = torch.from_numpy(synth_frames(3, 320, 384, seed=5, kind="blocks")).cuda()
+    assert torch.equal(fused.head_raw(frames), plain.head_raw(frames))
+
+
+def test_head_lanes_run_the_same_kernels_beside_each_other():
+    """Option head_lanes (default 1): the Detect head's chains leave the caller's stream (side streams, event fork/join).
+    Same kernels and arguments, so detections and the raw head output are bit-identical to the in-order run, call after
+    call (a missing dependency edge would show as a race)."""
+    sd, meta = synth_state_dict("detect", NC, "m", 0, nc_quirk=False), synth_meta("detect", NC, "m", False)
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    frames = torch.from_numpy(synth_frames(8, 640, 640, seed=9, kind="noise")).cuda()
+    eng.set_option("head_lanes", 0)
+    y0 = eng.head_raw(frames).clone()
+    d0, c0, a0 = [t.clone() for t in eng.detect(frames, conf=0.25, iou=0.7)]
+    eng.set_option("head_lanes", 1)
+    for i in range(6):
+        assert torch.equal(eng.head_raw(frames), y0), f"replay {i}"
+        d, c, a = eng.detect(frames, conf=0.25, iou=0.7)
+        assert torch.equal(d, d0) and torch.equal(c, c0) and torch.equal(a, a0)
