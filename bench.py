@@ -266,6 +266,7 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
         rl = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
               "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "traffic_source": tsrc, "launches": n,
               "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "algorithmic_bytes_per_launch": round(by / n),
+              "timing": "HIP events around every launch, ops in order on one stream (profile mode keeps the head chains on the caller's stream)",
               "share_of_step_kernel_time": round(ms / total_ms, 3),
               "all_convs_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None}
     else:

@@ -16,7 +16,7 @@ scale = sys.argv[2] if len(sys.argv) > 2 else "m"
 sd, meta = synth_state_dict("detect", 64, scale, 0), synth_meta("detect", 64, scale)
 calib = torch.from_numpy(np.concatenate([synth_frames(4, sz, sz, seed=101), synth_frames(2, sz, sz, seed=102, kind="blocks")]))
 e8 = engine_from_weights(sd, meta, "f8", 0, bgr_input=False, calib_frames=calib)
-e16 = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+e16 = engine_from_weights(sd, meta, "f16", 0, bgr_input=False, fuse_head=False)   # same op list as the fp8 program
 frames = torch.from_numpy(synth_frames(2, sz, sz, seed=1)).cuda()
 y8 = e8.head_raw(frames); y16 = e16.head_raw(frames)
 for i, op in enumerate(e16.prog.ops):

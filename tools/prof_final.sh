@@ -6,6 +6,10 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-exact-f32 > $R/gpurun_out/prof_$TAG.log 2>&1 && echo stats-ok
+# the same command with the Detect head's chains kept on the caller's stream: kernels do not overlap, so per-kernel average
+# durations are comparable with bench.py's per-op event timing (its roofline block runs in that mode)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_inorder -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-exact-f32 --opt head_lanes=0 > $R/gpurun_out/prof_${TAG}_inorder.log 2>&1 && echo stats-inorder-ok
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_cls -- python3 $R/bench.py --workload classify --steps 200 --warmup 20 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_${TAG}_cls.log 2>&1 && echo stats-cls-ok
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_f8 -- python3 $R/bench.py --dtype f8 --imgsz 1280 --batch 16 --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-exact-f32 > $R/gpurun_out/prof_${TAG}_f8.log 2>&1 && echo stats-f8-ok
 cd $R && bash tools/pmc_profile.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1; tail -2 gpurun_out/pmc_$TAG.log
 PMC_GROUPS="sq1 fetch write" bash tools/pmc_profile.sh ${TAG}_f8 --dtype f8 --imgsz 1280 --batch 16 > gpurun_out/pmc_${TAG}_f8.log 2>&1; tail -1 gpurun_out/pmc_${TAG}_f8.log
