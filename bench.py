@@ -254,9 +254,17 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
         key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
-        if key in tj["kernels"] and tj.get("workload") == [B, H, W, dtype]:
-            traffic = round(tj["kernels"][key]["traffic_bytes_per_launch"])
-            tsrc = "profiles/r02_traffic.json (rocprofv3 --pmc passes, committed; not re-measured by this run)"
+        if tj.get("workload") == [B, H, W, dtype]:
+            if key in tj["kernels"]:
+                traffic = round(tj["kernels"][key]["traffic_bytes_per_launch"])
+            elif name.startswith("conv_h2<"):
+                # rocprofv3 names the halo-slab kernel per tile geometry (conv_h2<dtype,tc,geo>): launch-weighted mean over them
+                tc = name[name.index(",tc") + 3:-1]
+                ks = [v for k, v in tj["kernels"].items() if k.startswith(f"conv_h2<{dtype},{tc},")]
+                if ks:
+                    traffic = round(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
+            if traffic is not None:
+                tsrc = "profiles/r02_traffic.json (rocprofv3 --pmc passes, committed; not re-measured by this run)"
     except Exception:
         pass
     total_ms = sum(v[1] for v in per.values())

@@ -5,12 +5,12 @@ usage: python tools/per_layer_table.py perop.json dtype(f16|f32) out.md"""
 import json
 import sys
 
-PEAK = {"f16": 2500e12, "f32": 157.3e12}
+PEAK = {"f16": 2500e12, "f32": 157.3e12, "f8": 5000e12}
 HBM = 8e12
 src, dt, out = sys.argv[1], sys.argv[2], sys.argv[3]
 ops = json.load(open(src))["by_op"]
 kinds = {0: "stem", 1: "conv", 2: "maxpool5", 3: "decode", 4: "cls_head"}
-lines = [f"# Per-layer times and roofline fractions ({dt}, yolov8m 640x640 batch 64, one MI355X; from `bench.py --profile-out`)", "",
+lines = [f"# Per-layer times and roofline fractions ({dt}, yolov8m, one MI355X, the workload of the json; from `bench.py --profile-out`)", "",
          "| layer | op | k | cin->cout | /stride | kernel cfg | us | TFLOP/s | GB/s (compulsory) | bound | frac of own roofline |", "|" + "---|" * 11]
 tot_ms = tot_min = 0.0
 for o in ops:
