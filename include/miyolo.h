@@ -157,6 +157,17 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
 /* Replaces: the forward up to Detect's return value `y` ([3P] Detect._inference):
  * y float [B, 4+nc, A] = (cx,cy,w,h in network pixels, sigmoid class scores). The parity
  * gate on head values (1e-4 vs the CPU path) reads this. */
+/* Option "nms_async" = 1 (default 0): miyolo_detect enqueues its score filter + NMS on an internal stream behind the
+ * decode and does NOT join the caller's stream, so the next call's backbone runs beside it (the NMS is one workgroup per
+ * image: 64 of 256 CUs for ~0.4 ms at batch 64).  The outputs of the call are then complete only after
+ * miyolo_wait_outputs(h, stream), which orders `stream` behind the most recent NMS (an event wait, no host
+ * synchronisation); a later call's decode, and every other entry point that uses the workspace, waits by itself.
+ * Ignored while "graph", "profile" or "batch_split" are on.  Measured on configuration 1: no gain (8 109 vs 8 262 frames/s) -
+ * the NMS workgroups hold 128 KiB of LDS and cannot share a CU with the conv kernels', so they only delay them; kept for
+ * callers whose next work is not LDS-bound.  With the option off (default) outputs are complete in stream
+ * order as before and miyolo_wait_outputs is a no-op. */
+int miyolo_wait_outputs(miyolo_handle h, void* stream);
+
 int miyolo_head_raw(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* y,
                     void* workspace, size_t workspace_bytes, void* stream);
 

@@ -87,6 +87,10 @@ struct miyolo_engine {
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
   std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
+  int nms_async = 0;        // detect: the NMS of a call on an internal stream, not joined (miyolo_wait_outputs); see miyolo.h
+  hipStream_t nms_stream = nullptr;
+  hipEvent_t ev_dec = nullptr, ev_nms = nullptr;
+  bool nms_pending = false;
   int head_lanes = 1;       // detect: the Detect head's independent conv chains on side streams (build_lanes)
   std::vector<int> op_lane;                 // lane of each op (0 = the caller's stream)
   std::vector<std::vector<int>> op_waits;   // ops on OTHER lanes op i must wait for (latest per lane)
@@ -602,6 +606,7 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
       if (h->op_lane[i] > 0) si = h->lanes[h->op_lane[i] - 1];
       for (int pi : h->op_waits[i]) HIP_TRY(h, hipStreamWaitEvent(si, h->op_ev[pi], 0));
     }
+    if (h->nms_pending && h->ops[i].kind == MIYOLO_OP_DECODE) HIP_TRY(h, hipStreamWaitEvent(si, h->ev_nms, 0));   // it still reads y
     if (h->profile) {
       rec.cfg = conv_cfg_id(h, h->ops[i], p);
       HIP_TRY(h, hipEventCreate(&rec.e0));
@@ -639,6 +644,12 @@ int run_nms(miyolo_engine* h, const Plan& p, const float* y, int Bc, int A, floa
   hipLaunchKernelGGL(nms_prefilter_kernel, dim3((A + 255) / 256, Bc), dim3(256), 0, s, a);
   hipLaunchKernelGGL(nms_sort_greedy_kernel, dim3(Bc), dim3(kNmsThreads), (size_t)nms_lds_bytes(max_det), s, a);
   HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+// an asynchronous NMS of an earlier detect call may still use y and the NMS scratch: order this stream behind it
+int join_pending_nms(miyolo_engine* h, hipStream_t s) {
+  if (h->nms_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_nms, 0));
   return 0;
 }
 
@@ -917,6 +928,7 @@ void miyolo_destroy(miyolo_handle h) {
   for (hipStream_t st : h->lanes) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : h->lane_ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : h->op_ev) (void)hipEventDestroy(ev);
+  if (h->nms_stream) { (void)hipStreamSynchronize(h->nms_stream); (void)hipStreamDestroy(h->nms_stream); (void)hipEventDestroy(h->ev_dec); (void)hipEventDestroy(h->ev_nms); }
   for (hipStream_t st : h->split_streams) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : h->split_ev) (void)hipEventDestroy(ev);
   if (h->dbg) (void)hipFree(h->dbg);
@@ -937,6 +949,12 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes) {
   return (int)h->ops.size();
 }
 
+int miyolo_wait_outputs(miyolo_handle h, void* stream) {
+  if (!h) return MIYOLO_ERR_ARG;
+  DevGuard guard(h->device);
+  return join_pending_nms(h, static_cast<hipStream_t>(stream));
+}
+
 int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!h || !key) return MIYOLO_ERR_ARG;
   drop_graphs(h);                                    // every option can change which kernels a call launches
@@ -954,6 +972,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
   if (!strcmp(key, "cls_mega")) { h->cls_mega = value; return 0; }
   if (!strcmp(key, "head_lanes")) { h->head_lanes = value; return 0; }
+  if (!strcmp(key, "nms_async")) { h->nms_async = value; return 0; }
   if (!strcmp(key, "batch_split")) { h->batch_split = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }
@@ -1021,6 +1040,13 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
   const float* y = reinterpret_cast<const float*>(static_cast<unsigned char*>(workspace) + p.y_off);
   struct { int entry, B, H, W, agnostic, max_det; float conf, iou; const void* in; const void* scale; void* d; void* c; void* a; void* ws; hipStream_t s; }
       key = {1, B, H, W, agnostic, max_det, conf, iou, in, scale, out_dets, out_counts, out_anchor, workspace, s};
+  const bool async_nms = h->nms_async && !h->graph && !h->profile && h->batch_split <= 1;
+  if (async_nms && !h->nms_stream) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->nms_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_dec, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_nms, hipEventDisableTiming));
+  }
+  if (!async_nms) { if (int rc = join_pending_nms(h, s)) return rc; }
   return with_graph(h, s, &key, sizeof(key), [&]() -> int {
     const int K = h->batch_split;
     if (K > 1 && B == p.B && B % K == 0 && !h->profile) {
@@ -1060,9 +1086,19 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
       Plan pc = p;
       pc.B = std::min(p.B, B - b0);
       if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s)) return rc;
+      hipStream_t sn = s;
+      if (async_nms) {
+        HIP_TRY(h, hipEventRecord(h->ev_dec, s));
+        HIP_TRY(h, hipStreamWaitEvent(h->nms_stream, h->ev_dec, 0));
+        sn = h->nms_stream;
+      }
       if (int rc = run_nms(h, pc, y, pc.B, p.A, conf, iou, agnostic, max_det, scale ? scale + (size_t)b0 * 5 : nullptr,
                            out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
-                           out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, s)) return rc;
+                           out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, sn)) return rc;
+      if (async_nms) {
+        HIP_TRY(h, hipEventRecord(h->ev_nms, sn));
+        h->nms_pending = true;
+      }
     }
     return 0;
   });
@@ -1076,6 +1112,7 @@ int miyolo_head_raw(miyolo_handle h, const uint8_t* in, int B, int H, int W, flo
   if (int rc = prepare(h, B, H, W, workspace_bytes, workspace)) return rc;
   DevGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = join_pending_nms(h, s)) return rc;
   const Plan& p = h->plan;
   const size_t per = (size_t)(4 + h->desc.nc) * p.A;
   for (int b0 = 0; b0 < B; b0 += p.B) {
@@ -1101,6 +1138,7 @@ int miyolo_nms(miyolo_handle h, const float* y, int B, int A, int H, int W, floa
   if (A < 1 || A > h->plan.A) return fail(h, MIYOLO_ERR_SHAPE, "A=%d exceeds the %d anchors of a %dx%d frame", A, h->plan.A, H, W);
   DevGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = join_pending_nms(h, s)) return rc;
   const Plan& p = h->plan;
   const size_t per = (size_t)(4 + h->desc.nc) * p.A;
   for (int b0 = 0; b0 < B; b0 += p.B) {

@@ -93,19 +93,25 @@ class DetectionGather:
         p = self.payload[slot % self.depth]
         return p[: self.nd].view(self.b, self.max_det, 6), p[self.nd:].view(torch.int32), None
 
-    def launch(self, slot: int):
+    def launch(self, slot: int, ready=None):
+        """`ready(stream)`: optional hook that orders `stream` behind whatever still produces the payload off the current
+        stream (Engine.wait_outputs with option nms_async)."""
         k = slot % self.depth
         if not self.active:
             return
         if self.nccl:
             cur = torch.cuda.current_stream(self.device)
             self.side.wait_stream(cur)                       # the detections of this batch are complete
+            if ready is not None:
+                ready(self.side)
             with torch.cuda.stream(self.side):
                 dist.all_gather_into_tensor(self.gathered[k], self.payload[k], group=self.group)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             self.done[k] = ev
         else:
+            if ready is not None:
+                ready(None)
             dist.all_gather(list(self.gathered[k].chunk(self.world)), self.payload[k], group=self.group)
 
     def wait(self, slot: int):

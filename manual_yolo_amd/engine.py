@@ -61,6 +61,7 @@ SYMBOLS = {
     "miyolo_chunk": (_i, [_vp, _i, _i, _i]),
     "miyolo_classify_launches": (_i, [_vp, _i, _i, C.POINTER(_sz)]),
     "miyolo_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "miyolo_wait_outputs": (_i, [_vp, _vp]),
     "miyolo_set_classes": (_i, [_vp, _vp, _i]),
     "miyolo_detect": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "miyolo_head_raw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -267,8 +268,11 @@ class Engine:
     # ------------------------------------------------------------------ hot path
     def detect(self, frames: torch.Tensor, conf: float = 0.25, iou: float = 0.7, agnostic: bool = False,
                max_det: int = 300, scale: Optional[torch.Tensor] = None, want_anchor: bool = True,
-               out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None):
-        """frames uint8 [B,H,W,3] on the GPU -> (dets [B,max_det,6], counts [B], anchor [B,max_det])."""
+               out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, defer: bool = False):
+        """frames uint8 [B,H,W,3] on the GPU -> (dets [B,max_det,6], counts [B], anchor [B,max_det]).
+        With option nms_async the outputs are complete in stream order only after `wait_outputs()`; `defer=False`
+        (default) calls it here, so the call behaves as without the option; a pipelined caller passes `defer=True` and
+        waits where it consumes."""
         x, B, H, W = self._in(frames)
         ws = self.workspace(B, H, W)
         if out is None:
@@ -285,7 +289,14 @@ class Engine:
             self._graph_call(call)
         else:
             call()
+        if not defer:
+            self.wait_outputs()
         return dets, counts, anchor
+
+    def wait_outputs(self, stream: Optional["torch.cuda.Stream"] = None):
+        """Order `stream` (default: the current one) behind the most recent asynchronous NMS (option nms_async)."""
+        st = (stream.cuda_stream if stream is not None else self._stream())
+        self._check(self.lib.miyolo_wait_outputs(self.h, st), "miyolo_wait_outputs")
 
     def head_raw(self, frames: torch.Tensor) -> torch.Tensor:
         x, B, H, W = self._in(frames)

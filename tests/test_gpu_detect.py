@@ -372,3 +372,38 @@ def test_head_lanes_run_the_same_kernels_beside_each_other():
         assert torch.equal(eng.head_raw(frames), y0), f"replay {i}"
         d, c, a = eng.detect(frames, conf=0.25, iou=0.7)
         assert torch.equal(d, d0) and torch.equal(c, c0) and torch.equal(a, a0)
+
+
+def test_async_nms_pipelines_calls_without_changing_results():
+    """Option nms_async: a call's NMS runs on the library's internal stream and the next call's backbone beside it; outputs
+    are complete after wait_outputs().  Alternate two batches through two output slots without waiting in between (the
+    bench's pipelined loop) and compare with the synchronous results; also through the default detect() (implicit wait),
+    head_raw and a standalone nms call issued while an asynchronous NMS is still in flight."""
+    sd, meta = synth_state_dict("detect", NC, "m", 0, nc_quirk=False), synth_meta("detect", NC, "m", False)
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    fa = torch.from_numpy(synth_frames(8, 640, 640, seed=21, kind="noise")).cuda()
+    fb = torch.from_numpy(synth_frames(8, 640, 640, seed=22, kind="blocks")).cuda()
+    ref = {k: [t.clone() for t in eng.detect(f, conf=0.25, iou=0.7)] for k, f in (("a", fa), ("b", fb))}
+    ya = eng.head_raw(fa).clone()
+    eng.set_option("nms_async", 1)
+    slots = [[torch.empty_like(t) for t in ref["a"]] for _ in range(2)]
+    for i in range(8):
+        k, f = ("a", fa) if i % 2 == 0 else ("b", fb)
+        eng.detect(f, conf=0.25, iou=0.7, out=tuple(slots[i % 2]), defer=True)
+        if i >= 1:                                         # consume the PREVIOUS call's outputs while this one is in flight
+            pk = "b" if i % 2 == 0 else "a"
+            # wait_outputs orders behind the most recent NMS, which is later than the previous one: still a valid wait
+            eng.wait_outputs()
+            for got, want in zip(slots[(i - 1) % 2], ref[pk]):
+                assert torch.equal(got, want), f"call {i - 1}"
+    d, c, a = eng.detect(fa, conf=0.25, iou=0.7)           # default: implicit wait
+    assert torch.equal(d, ref["a"][0]) and torch.equal(c, ref["a"][1]) and torch.equal(a, ref["a"][2])
+    eng.detect(fb, conf=0.25, iou=0.7, out=tuple(slots[0]), defer=True)
+    assert torch.equal(eng.head_raw(fa), ya)               # overwrites y: must order itself behind the pending NMS
+    eng.wait_outputs()
+    assert torch.equal(slots[0][0], ref["b"][0]) and torch.equal(slots[0][1], ref["b"][1])
+    eng.detect(fb, conf=0.25, iou=0.7, out=tuple(slots[1]), defer=True)
+    d2, c2, a2 = eng.nms(ya, 640, 640, 0.25, 0.7)          # shares the NMS scratch with the pending one
+    assert torch.equal(d2, ref["a"][0]) and torch.equal(c2, ref["a"][1])
+    eng.wait_outputs()
+    assert torch.equal(slots[1][0], ref["b"][0])
