@@ -15,10 +15,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_total, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, tmp, n_total):
+    # file rendezvous and file results: no TCP port to race for, no queue feeder threads (both were seen to fail now and then
+    # on a loaded 8-core box)
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", init_method=f"file://{tmp}/rendezvous", rank=rank, world_size=world)
     lo, hi = shard_bounds(n_total, rank, world)
     bl = (n_total + world - 1) // world
     # fake per-frame detections: frame f has (f % 4) boxes whose first field is f
@@ -36,7 +37,8 @@ def _worker(rank, world, port, n_total, q):
         g.launch(step)
         fd, fc = g.wait(step)
         fused.append((fd.clone(), fc.clone()))
-    q.put((rank, gd.clone(), gc.clone(), fused))
+    torch.save((rank, gd.clone(), gc.clone(), fused), os.path.join(tmp, f"out{rank}.pt.tmp"))
+    os.replace(os.path.join(tmp, f"out{rank}.pt.tmp"), os.path.join(tmp, f"out{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,18 +52,32 @@ def test_shard_bounds_cover_everything():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
+def _run_world(world, n_total):
+    import shutil
+    import tempfile
+    ctx = mp.get_context("spawn")
+    tmp = tempfile.mkdtemp(prefix="miyolo_dist_")
+    try:
+        procs = [ctx.Process(target=_worker, args=(r, world, tmp, n_total)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=180)
+        if any(p.is_alive() for p in procs):
+            for p in procs:
+                p.kill()
+            return None
+        if any(p.exitcode != 0 for p in procs):
+            return None
+        return [torch.load(os.path.join(tmp, f"out{r}.pt"), weights_only=False) for r in range(world)]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def test_all_gather_detections_world2():
     world, n_total = 2, 7
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _run_world(world, n_total) or _run_world(world, n_total)      # one retry: process start-up on a busy box
+    assert got is not None, "the two gloo ranks did not finish"
     bl = 4
     for rank, gd, gc, fused in got:
         for step, (fd, fc) in enumerate(fused):            # one-message gather == two-collective gather
