@@ -238,7 +238,7 @@ hipError_t set_halo_attrs() {
 }
 #endif  // MIYOLO_EXPERIMENTS
 
-int nms_lds_bytes(int max_det) { return ((max_det * 5 * 4 + 15) & ~15) + kNmsLdsKeys * 8; }
+int nms_lds_bytes(int max_det) { return nms_keys_offset(max_det) + kNmsLdsKeys * 8; }
 
 // Largest number of images per pass such that every buffer stays below 2 GiB (the kernels use
 // 32-bit byte offsets, and raw-buffer loads use offset 0x80000000 as the "reads zero" marker).

@@ -20,8 +20,9 @@
 // anchors), candidates append a 64-bit key (score bits << 32 | ~anchor) to the image's list
 // with one atomic; (2) one workgroup per image sorts its keys (bitonic, in LDS when they fit)
 // and wave 0 runs the greedy pass 64 candidates at a time: each lane tests its candidate
-// against the kept list (LDS broadcast reads), then the 64 survivors are resolved with
-// ballot + shuffles.  The greedy pass stops as soon as max_det boxes are kept.
+// against the kept boxes of its class (per-class chains in LDS), then the 64 survivors are resolved with
+// ballot + shuffles; the next chunk's box gathers are issued before the current chunk is resolved.
+// The greedy pass stops as soon as max_det boxes are kept.
 #pragma once
 #include "common.h"
 
@@ -95,11 +96,17 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
   return ovr > thr;
 }
 
+constexpr int kNmsHeads = 256;       // per-class kept lists for up to this many classes (more: one list, as agnostic)
+
+// LDS layout of nms_sort_greedy_kernel: kept[max_det][5] floats | next[max_det] | head[kNmsHeads] | keys[kNmsLdsKeys]
+__host__ __device__ inline int nms_keys_offset(int max_det) { return ((max_det * 5 * 4 + 15) & ~15) + ((max_det * 4 + 15) & ~15) + kNmsHeads * 4; }
+
 __global__ __launch_bounds__(kNmsThreads) void nms_sort_greedy_kernel(const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
-  // layout: kept[max_det][5] floats | keys[kNmsLdsKeys] (only when used)
   float* kept = reinterpret_cast<float*>(nsm);
-  unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(nsm + ((a.max_det * 5 * 4 + 15) & ~15));
+  int* nextk = reinterpret_cast<int*>(nsm + ((a.max_det * 5 * 4 + 15) & ~15));
+  int* head = nextk + ((a.max_det * 4 + 15) & ~15) / 4;
+  unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(nsm + nms_keys_offset(a.max_det));
   const int b = blockIdx.x, tid = threadIdx.x;
   int n = a.count[b];
   if (n > a.A) n = a.A;
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_sort_greedy_kernel(const NmsA
   int npad = 1;
   while (npad < n) npad <<= 1;
   const bool in_lds = npad <= kNmsLdsKeys;
+  if (tid < kNmsHeads) head[tid] = -1;
   if (n > 1) {
     if (in_lds) {
       for (int i = tid; i < npad; i += kNmsThreads) lkeys[i] = (i < n) ? gkeys[i] : 0ull;
@@ -118,8 +126,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_sort_greedy_kernel(const NmsA
       __syncthreads();
       bitonic_sort_desc(gkeys, npad, tid, kNmsThreads);
     }
-  } else if (n == 1) {
-    if (tid == 0) lkeys[0] = gkeys[0];
+  } else {
+    if (n == 1 && tid == 0) lkeys[0] = gkeys[0];
     __syncthreads();
   }
   if (tid >= 64) return;          // greedy pass: wave 0 only
@@ -133,28 +141,61 @@ __global__ __launch_bounds__(kNmsThreads) void nms_sort_greedy_kernel(const NmsA
     g = a.scale[b * 5 + 0]; px = a.scale[b * 5 + 1]; py = a.scale[b * 5 + 2];
     ow = a.scale[b * 5 + 3]; oh = a.scale[b * 5 + 4];
   }
-  int nk = 0;
-  for (int s = 0; s < n && nk < a.max_det; s += 64) {
+  // Kept boxes are chained per class (head[class] -> newest kept box of the class, nextk[] -> the one before it): boxes of
+  // different classes are 7680 apart after the class offset, their IoU is 0 and can never exceed the threshold, so a
+  // candidate only has to be tested against the kept boxes of ITS class - the same decisions as testing against all of
+  // them (oracle/post_ref.py does), at 1/10th of the work on crowded frames.  Agnostic mode (no offset): one chain.
+  const bool one_list = a.agnostic || a.nc > kNmsHeads;
+  struct Cand { unsigned an; float score, cx, cy, w, h; int ci; bool has; };
+  auto fetch = [&](int s) {
+    Cand c;
     const int idx = s + lane;
-    const bool has = idx < n;
+    c.has = idx < n;
     unsigned long long key = 0ull;
-    if (has) key = (in_lds || n == 1) ? lkeys[idx] : gkeys[idx];
-    const unsigned an = has ? (0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0u;
-    const float score = __uint_as_float((unsigned)(key >> 32));
-    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, cf = 0.f;
-    if (has) {
-      const float cx = yb[0L * a.A + an], cy = yb[1L * a.A + an];
-      const float hw = yb[2L * a.A + an] / 2.0f, hh = yb[3L * a.A + an] / 2.0f;
-      x1 = cx - hw; y1 = cy - hh; x2 = cx + hw; y2 = cy + hh;
-      cf = (float)a.cls_idx[(long)b * a.A + an];
+    if (c.has) key = (in_lds || n == 1) ? lkeys[idx] : gkeys[idx];
+    c.an = c.has ? (0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0u;
+    c.score = __uint_as_float((unsigned)(key >> 32));
+    c.cx = c.cy = c.w = c.h = 0.f; c.ci = 0;
+    if (c.has) {
+      c.cx = yb[0L * a.A + c.an]; c.cy = yb[1L * a.A + c.an];
+      c.w = yb[2L * a.A + c.an]; c.h = yb[3L * a.A + c.an];
+      c.ci = a.cls_idx[(long)b * a.A + c.an];
     }
+    return c;
+  };
+  int nk = 0;
+  // the gathers (scattered 4-byte reads of y: an L2 / HBM latency each) of the next three chunks fly while one is resolved
+  Cand q0 = fetch(0), q1 = fetch(64), q2 = fetch(128);
+  for (int s = 0; s < n && nk < a.max_det; s += 64) {
+    const Cand cur = q0;
+    q0 = q1; q1 = q2;
+    q2 = fetch(s + 192);
+    const bool has = cur.has;
+    const unsigned an = cur.an;
+    const float score = cur.score;
+    const float hw = cur.w / 2.0f, hh = cur.h / 2.0f;
+    const float x1 = cur.cx - hw, y1 = cur.cy - hh, x2 = cur.cx + hw, y2 = cur.cy + hh;
+    const float cf = (float)cur.ci;
+    const int li = one_list ? 0 : cur.ci;
     const float c = a.agnostic ? cf * 0.0f : cf * kMaxWh;
     const float ox1 = x1 + c, oy1 = y1 + c, ox2 = x2 + c, oy2 = y2 + c;
     const float area = (ox2 - ox1) * (oy2 - oy1);
     bool alive = has;
-    for (int k = 0; k < nk; ++k) {
-      const float* kb = kept + k * 5;
-      if (alive && iou_gt(kb[0], kb[1], kb[2], kb[3], kb[4], ox1, oy1, ox2, oy2, area, a.iou)) alive = false;
+    if (one_list) {
+      // one chain = every kept box: walk the array instead (wave-uniform addresses: broadcast reads, no pointer chase)
+      for (int k = 0; k < nk; ++k) {
+        const float* kb = kept + k * 5;
+        if (alive && iou_gt(kb[0], kb[1], kb[2], kb[3], kb[4], ox1, oy1, ox2, oy2, area, a.iou)) alive = false;
+      }
+    } else {
+      int k = has ? head[li] : -1;
+      while (__any(k >= 0)) {
+        if (k >= 0) {
+          const float* kb = kept + k * 5;
+          if (iou_gt(kb[0], kb[1], kb[2], kb[3], kb[4], ox1, oy1, ox2, oy2, area, a.iou)) { alive = false; k = -1; }
+          else k = nextk[k];
+        }
+      }
     }
     unsigned long long mask = __ballot(alive);
     while (mask) {
@@ -164,6 +205,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_sort_greedy_kernel(const NmsA
       if (lane == j) {
         float* kb = kept + nk * 5;
         kb[0] = ox1; kb[1] = oy1; kb[2] = ox2; kb[3] = oy2; kb[4] = area;
+        nextk[nk] = head[li];
+        head[li] = nk;
         float rx1 = x1, ry1 = y1, rx2 = x2, ry2 = y2;
         if (a.scale) {
           rx1 = fminf(fmaxf((rx1 - px) / g, 0.f), ow); ry1 = fminf(fmaxf((ry1 - py) / g, 0.f), oh);
