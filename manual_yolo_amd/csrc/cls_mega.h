@@ -52,8 +52,9 @@ struct MegaArgs {
   int32_t pool_off;                         // fp32 scratch for pooled features + logits
   int32_t ring_off;                         // kMegaWaves weight rings of kMegaPf KiB
   int32_t bias_off;                         // kMegaWaves x 2 bias slots of 256 B
+  int32_t desc_off;                         // the layer table, copied to LDS once (reads of it never touch the scalar cache)
+  const MegaOp* ops_dev;                    // the same table in device memory
   unsigned long long* stamps;               // option dbg_op: cycle counter after every layer, first 8 images x 32 slots
-  MegaOp ops[kMegaMaxOps];
 };
 
 // A wave's weight stream: a private LDS ring of kMegaPf slots (1 KiB = 64 lanes x 16 B each) always holds the next kMegaPf K
@@ -365,11 +366,29 @@ __global__ __launch_bounds__(kMegaWaves * 64) void cls_mega_kernel(const MegaArg
   const uint32_t ring = (uint32_t)(a.ring_off + wave * (kMegaPf * 1024));   // this wave's weight ring
   const uint32_t bring = (uint32_t)(a.bias_off + wave * 512);              // and its two bias slots
   int bsel = 0;
-  MegaOp op = a.ops[0];
-  MegaOp nxo = a.ops[a.nops > 1 ? 1 : 0];
+  // layer table -> LDS (one coalesced copy); a wave reads a descriptor with broadcast LDS reads and pins the values to
+  // SGPRs.  From the kernel arguments each descriptor was ~30 scalar loads whose latency the SGPR spill code exposed at
+  // every layer (~1 k cycles x 26 layers).
+  {
+    constexpr int kDw = (int)(sizeof(MegaOp) / 4);
+    const int32_t* src = reinterpret_cast<const int32_t*>(a.ops_dev);
+    int32_t* dst = reinterpret_cast<int32_t*>(smem + a.desc_off);
+    for (int i = tid; i < a.nops * kDw; i += kMegaWaves * 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  auto desc = [&](int oi) {
+    constexpr int kDw = (int)(sizeof(MegaOp) / 4);
+    const int32_t* p = reinterpret_cast<const int32_t*>(smem + a.desc_off) + oi * kDw;
+    MegaOp o;
+    int32_t* q = reinterpret_cast<int32_t*>(&o);
+#pragma unroll
+    for (int i = 0; i < kDw; ++i) q[i] = __builtin_amdgcn_readfirstlane(p[i]);
+    return o;
+  };
+  MegaOp op = desc(0);
+  MegaOp nxo = desc(a.nops > 1 ? 1 : 0);
   for (int oi = 0; oi < a.nops; ++oi) {
     const bool has = oi + 1 < a.nops;
-    const MegaOp nno = a.ops[oi + 2 < a.nops ? oi + 2 : oi];               // layer descriptors are fetched two layers ahead
     const MegaStream nx = mega_first_item(nxo, has, wave, lane);
     if (op.zero_rows > 0) {
       // a buffer a 3x3 conv will read starts its life: clear its halo ring (disjoint from what this layer writes)
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(kMegaWaves * 64) void cls_mega_kernel(const MegaArg
     mega_barrier();
     if (a.stamps && img < 8 && tid == 0) a.stamps[img * 32 + oi] = __builtin_readcyclecounter();
     op = nxo;
-    nxo = nno;
+    nxo = desc(oi + 2 < a.nops ? oi + 2 : oi);
   }
   mega_drain();
   // ---- Classify tail (arithmetic order of cls_head_kernel): avg-pool -> Linear -> softmax

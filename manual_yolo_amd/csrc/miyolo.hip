@@ -80,6 +80,8 @@ struct miyolo_engine {
   int mega_h = 0, mega_w = 0, mega_ok = 0;
   size_t mega_lds = 0;
   void* mega_wbuf = nullptr;   // conv weights in MFMA fragment order (mega_repack_kernel)
+  void* mega_ops_dev = nullptr;   // the layer table in device memory
+  std::vector<MegaOp> mega_ops;
   int cls_streams = 1;      // classify: sub-batches on this many internal streams, joined by events.  Measured at batch 256: 1 stream
                             // 1.12 M img/s, 2: 0.85 M, 4: 0.40 M, 8: 0.29 M (captured in a hipGraph: 0.88 / 0.84 / 0.57 / 0.42 M) - the
                             // front end takes ~8 us per dispatch whether or not the chains are independent; only fewer launches help
@@ -745,10 +747,11 @@ bool build_mega(miyolo_engine* h, int H, int W) {
     }
   MegaArgs& m = h->mega;
   memset(&m, 0, sizeof(m));
+  h->mega_ops.assign((size_t)(nops - 1), MegaOp{});
   m.H = H; m.W = W; m.nc = h->desc.nc; m.nops = nops - 1;
   for (int i = 0; i < nops - 1; ++i) {
     const miyolo_op& op = h->ops[i];
-    MegaOp& o = m.ops[i];
+    MegaOp& o = h->mega_ops[i];
     const int db = op.dst.buf;
     if (db <= 0) return false;
     const miyolo_buf& ob = h->bufs[db];
@@ -794,16 +797,18 @@ bool build_mega(miyolo_engine* h, int H, int W) {
   peak = m.ring_off + (size_t)kMegaWaves * kMegaPf * 1024;
   m.bias_off = (int)peak;
   peak += (size_t)kMegaWaves * 512;
+  m.desc_off = (int)align_up(peak, 16);
+  peak = m.desc_off + sizeof(MegaOp) * (size_t)(nops - 1);
   m.lin_w = static_cast<const float*>(h->weights[hd.weight]); m.lin_b = static_cast<const float*>(h->weights[hd.bias]);
   if (peak > 160 * 1024) return false;
   // weights of the convs in fragment order (one buffer; repacked on the engine's device, default stream, synchronous)
   size_t wtot = 0;
-  for (int i = 1; i < nops - 1; ++i) wtot += align_up((size_t)m.ops[i].wbytes, 256);
+  for (int i = 1; i < nops - 1; ++i) wtot += align_up((size_t)h->mega_ops[i].wbytes, 256);
   if (h->mega_wbuf) { (void)hipFree(h->mega_wbuf); h->mega_wbuf = nullptr; }
   if (hipMalloc(&h->mega_wbuf, wtot) != hipSuccess) return false;
   size_t wo = 0;
   for (int i = 1; i < nops - 1; ++i) {
-    MegaOp& o = m.ops[i];
+    MegaOp& o = h->mega_ops[i];
     half_t* dst = reinterpret_cast<half_t*>(static_cast<char*>(h->mega_wbuf) + wo);
     const int total = (o.cout / 16) * (o.kpad / 32) * 64;
     hipLaunchKernelGGL(mega_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0,
@@ -811,6 +816,10 @@ bool build_mega(miyolo_engine* h, int H, int W) {
     o.w = dst;
     wo += align_up((size_t)o.wbytes, 256);
   }
+  if (h->mega_ops_dev) { (void)hipFree(h->mega_ops_dev); h->mega_ops_dev = nullptr; }
+  if (hipMalloc(&h->mega_ops_dev, sizeof(MegaOp) * (size_t)(nops - 1)) != hipSuccess) return false;
+  if (hipMemcpy(h->mega_ops_dev, h->mega_ops.data(), sizeof(MegaOp) * (size_t)(nops - 1), hipMemcpyHostToDevice) != hipSuccess) return false;
+  m.ops_dev = static_cast<const MegaOp*>(h->mega_ops_dev);
   if (hipDeviceSynchronize() != hipSuccess) return false;
   h->mega_lds = peak;
   h->mega_ok = 1;
@@ -933,6 +942,7 @@ void miyolo_destroy(miyolo_handle h) {
   for (hipEvent_t ev : h->split_ev) (void)hipEventDestroy(ev);
   if (h->dbg) (void)hipFree(h->dbg);
   if (h->mega_wbuf) (void)hipFree(h->mega_wbuf);
+  if (h->mega_ops_dev) (void)hipFree(h->mega_ops_dev);
   delete h;
 }
 
