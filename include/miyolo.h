@@ -154,9 +154,6 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
                   int32_t* out_counts, int32_t* out_anchor, void* workspace, size_t workspace_bytes,
                   void* stream);
 
-/* Replaces: the forward up to Detect's return value `y` ([3P] Detect._inference):
- * y float [B, 4+nc, A] = (cx,cy,w,h in network pixels, sigmoid class scores). The parity
- * gate on head values (1e-4 vs the CPU path) reads this. */
 /* Option "nms_async" = 1 (default 0): miyolo_detect enqueues its score filter + NMS on an internal stream behind the
  * decode and does NOT join the caller's stream, so the next call's backbone runs beside it (the NMS is one workgroup per
  * image: 64 of 256 CUs for ~0.4 ms at batch 64).  The outputs of the call are then complete only after
@@ -168,6 +165,9 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
  * order as before and miyolo_wait_outputs is a no-op. */
 int miyolo_wait_outputs(miyolo_handle h, void* stream);
 
+/* Replaces: the forward up to Detect's return value `y` ([3P] Detect._inference):
+ * y float [B, 4+nc, A] = (cx,cy,w,h in network pixels, sigmoid class scores). The parity
+ * gate on head values (1e-4 vs the CPU path) reads this. */
 int miyolo_head_raw(miyolo_handle h, const uint8_t* in, int B, int H, int W, float* y,
                     void* workspace, size_t workspace_bytes, void* stream);
 
