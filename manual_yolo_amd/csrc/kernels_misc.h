@@ -221,6 +221,13 @@ struct DecodeArgs {
   int32_t lh[3], lw[3], lstride[3], aoff[3];   // per level grid, stride, first anchor index
   int32_t nlevel, nc, A, B;
   float* y;
+  // optional fused score filter of the NMS (nms.h, nms_prefilter_kernel - same compares, same key): keys != null
+  unsigned long long* keys;       // [B, P]
+  int32_t* count;                 // [B], zeroed before this launch
+  int32_t* cls_idx;               // [B, A]
+  int32_t P, use_mask;
+  float conf;
+  uint32_t cls_mask[8];
 };
 
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
@@ -279,7 +286,29 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     }
     for (int c = grp; c < a.nc; c += 4) {
       const float v = sm[an * ldr + 64 + c];
-      yb[(long)(4 + c) * a.A + an] = 1.0f / (1.0f + expf(-v));
+      const float sg = 1.0f / (1.0f + expf(-v));
+      yb[(long)(4 + c) * a.A + an] = sg;
+      if (a.keys) sm[an * ldr + 64 + c] = sg;           // each word is read and rewritten by the same thread
+    }
+  }
+  if (!a.keys) return;
+  // fused NMS score filter: the class scores of the 64 anchors are still in LDS - the separate pass would read all of y
+  // back (137 MB at batch 64).  First arg-max in class order, `classes=` mask, strict > conf: nms_prefilter_kernel's rules
+  __syncthreads();
+  if (grp == 0 && an < na) {
+    const float* sc = sm + an * ldr + 64;
+    float best = sc[0];
+    int j = 0;
+    for (int c = 1; c < a.nc; ++c) {
+      const float v = sc[c];
+      if (v > best) { best = v; j = c; }
+    }
+    if (a.use_mask && !((a.cls_mask[j >> 5] >> (j & 31)) & 1u)) return;
+    if (best > a.conf) {
+      const int ag = a.aoff[lvl] + a0 + an;
+      const int slot = atomicAdd(a.count + b, 1);
+      a.keys[(long)b * a.P + slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ag);
+      a.cls_idx[(long)b * a.A + ag] = j;
     }
   }
 }

@@ -89,6 +89,9 @@ struct miyolo_engine {
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
   std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
+  int fuse_pre = 0;         // set by miyolo_detect around run_ops: the decode op also runs the NMS score filter
+  int fuse_pre_opt = 1;     // option "fuse_prefilter"
+  float fuse_conf = 0.f;
   int nms_async = 0;        // detect: the NMS of a call on an internal stream, not joined (miyolo_wait_outputs); see miyolo.h
   hipStream_t nms_stream = nullptr;
   hipEvent_t ev_dec = nullptr, ev_nms = nullptr;
@@ -465,6 +468,14 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
         nblk += (a.lh[l] * a.lw[l] + 63) / 64;
       }
       a.y = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + p.y_off);
+      if (h->fuse_pre) {
+        unsigned char* w8 = static_cast<unsigned char*>(ws);
+        a.keys = reinterpret_cast<unsigned long long*>(w8 + p.keys_off);
+        a.count = reinterpret_cast<int32_t*>(w8 + p.count_off);
+        a.cls_idx = reinterpret_cast<int32_t*>(w8 + p.cls_off);
+        a.P = p.P; a.conf = h->fuse_conf; a.use_mask = h->use_cls_mask;
+        for (int i = 0; i < 8; ++i) a.cls_mask[i] = h->cls_mask[i];
+      }
       const size_t lds = (size_t)64 * (64 + a.nc + 1) * 4;
       hipLaunchKernelGGL(decode_kernel, dim3(nblk, Bc), dim3(256), lds, s, a);
       break;
@@ -631,7 +642,7 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
 
 int run_nms(miyolo_engine* h, const Plan& p, const float* y, int Bc, int A, float conf, float iou, int agnostic,
             int max_det, const float* scale, float* out_dets, int32_t* out_counts, int32_t* out_anchor,
-            void* ws, hipStream_t s) {
+            void* ws, hipStream_t s, bool prefiltered = false) {
   NmsArgs a;
   a.y = y; a.B = Bc; a.A = A; a.nc = h->desc.nc; a.max_det = max_det; a.agnostic = agnostic; a.P = p.P;
   a.conf = conf; a.iou = iou; a.scale = scale;
@@ -642,8 +653,10 @@ int run_nms(miyolo_engine* h, const Plan& p, const float* y, int Bc, int A, floa
   a.out_dets = out_dets; a.out_counts = out_counts; a.out_anchor = out_anchor;
   for (int i = 0; i < 8; ++i) a.cls_mask[i] = h->cls_mask[i];
   a.use_mask = h->use_cls_mask;
-  HIP_TRY(h, hipMemsetAsync(a.count, 0, (size_t)Bc * 4, s));
-  hipLaunchKernelGGL(nms_prefilter_kernel, dim3((A + 255) / 256, Bc), dim3(256), 0, s, a);
+  if (!prefiltered) {       // else: the decode op filled keys / count / cls_idx (decode_kernel's fused filter)
+    HIP_TRY(h, hipMemsetAsync(a.count, 0, (size_t)Bc * 4, s));
+    hipLaunchKernelGGL(nms_prefilter_kernel, dim3((A + 255) / 256, Bc), dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(nms_sort_greedy_kernel, dim3(Bc), dim3(kNmsThreads), (size_t)nms_lds_bytes(max_det), s, a);
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -983,6 +996,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "cls_mega")) { h->cls_mega = value; return 0; }
   if (!strcmp(key, "head_lanes")) { h->head_lanes = value; return 0; }
   if (!strcmp(key, "nms_async")) { h->nms_async = value; return 0; }
+  if (!strcmp(key, "fuse_prefilter")) { h->fuse_pre_opt = value; return 0; }
   if (!strcmp(key, "batch_split")) { h->batch_split = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }
@@ -1095,7 +1109,16 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
     for (int b0 = 0; b0 < B; b0 += p.B) {
       Plan pc = p;
       pc.B = std::min(p.B, B - b0);
-      if (int rc = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s)) return rc;
+      // the decode op runs the NMS score filter while the class scores are still in LDS (decode_kernel); its candidate
+      // counters are zeroed first.  Not with the asynchronous NMS, whose previous instance may still read them.
+      const bool fused = !async_nms && h->fuse_pre_opt;
+      if (fused) {
+        HIP_TRY(h, hipMemsetAsync(static_cast<unsigned char*>(workspace) + p.count_off, 0, (size_t)pc.B * 4, s));
+        h->fuse_pre = 1; h->fuse_conf = conf;
+      }
+      const int rc_ops = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s);
+      h->fuse_pre = 0;
+      if (rc_ops) return rc_ops;
       hipStream_t sn = s;
       if (async_nms) {
         HIP_TRY(h, hipEventRecord(h->ev_dec, s));
@@ -1104,7 +1127,7 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
       }
       if (int rc = run_nms(h, pc, y, pc.B, p.A, conf, iou, agnostic, max_det, scale ? scale + (size_t)b0 * 5 : nullptr,
                            out_dets + (size_t)b0 * max_det * 6, out_counts + b0,
-                           out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, sn)) return rc;
+                           out_anchor ? out_anchor + (size_t)b0 * max_det : nullptr, workspace, sn, fused)) return rc;
       if (async_nms) {
         HIP_TRY(h, hipEventRecord(h->ev_nms, sn));
         h->nms_pending = true;
