@@ -206,7 +206,8 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * layer; bit-identical results), "head_lanes" (1 default: detect runs the Detect head's independent conv chains - per level
  * the first conv and the box / class branches behind it - on internal side streams, forked and joined by events around
  * the caller's stream; 0: everything in order on the caller's stream; same kernels, same results), "fuse_prefilter" (1
- * default: miyolo_detect's decode kernel also runs the NMS score filter; 0: separate pass; same results), "batch_split" (0 default;
+ * default: miyolo_detect's decode kernel also runs the NMS score filter; 0: separate pass; same results), "sppf_fuse" (1
+ * default: three chained MAXPOOL5 ops run as one launch; same results), "batch_split" (0 default;
  * K > 1: a batch that fits one pass runs as K part batches on K streams when the workspace holds K part plans - measured
  * +0.8..1.4 % on configuration 1, left off), "cls_streams" (1 default:
  * > 1 makes miyolo_classify fork the batch over that many internal streams, joined by events - measured slower), and the

@@ -164,6 +164,49 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const PoolArgs a) {
   *reinterpret_cast<vec_t*>(dp + (((long)b * a.H + h) * a.W + w) * a.dst_ld + a.dst_choff + cc * CE) = best;
 }
 
+// SPPF's three chained pools as ONE launch: pool5(x), pool5(pool5(x)), pool5(pool5(pool5(x))) for one image and one
+// 16-byte channel chunk per workgroup, the map ping-ponged through LDS (row max, then column max - a 5x5 window max is
+// separable, and max is exact, so the three outputs are bit-identical to three maxpool5_kernel launches); the input is
+// read once instead of three times through 25-tap gathers.
+struct Sppf3Args {
+  const void* src; void* dst[3];
+  int32_t src_ld, src_choff, dst_ld[3], dst_choff[3], ch, B, H, W;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf3_kernel(const Sppf3Args a) {
+  constexpr int CE = DT<T>::CE;
+  typedef T vec_t __attribute__((ext_vector_type(CE)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+  const int hw = a.H * a.W;
+  vec_t* A = reinterpret_cast<vec_t*>(sp_lds);
+  vec_t* Bf = A + hw;
+  const int cc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const T* sp = reinterpret_cast<const T*>(a.src);
+  for (int p = tid; p < hw; p += 256) A[p] = *reinterpret_cast<const vec_t*>(sp + ((long)b * hw + p) * a.src_ld + a.src_choff + cc * CE);
+  __syncthreads();
+  for (int st = 0; st < 3; ++st) {
+    for (int p = tid; p < hw; p += 256) {
+      const int y = p / a.W, x = p - y * a.W;
+      vec_t m = A[p];
+#pragma unroll
+      for (int dx = -2; dx <= 2; ++dx) { const int xx = x + dx; if (dx != 0 && xx >= 0 && xx < a.W) m = __builtin_elementwise_max(m, A[y * a.W + xx]); }
+      Bf[p] = m;
+    }
+    __syncthreads();
+    T* dp = reinterpret_cast<T*>(a.dst[st]);
+    for (int p = tid; p < hw; p += 256) {
+      const int y = p / a.W;
+      vec_t m = Bf[p];
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) { const int yy = y + dy; if (dy != 0 && yy >= 0 && yy < a.H) m = __builtin_elementwise_max(m, Bf[p + dy * a.W]); }
+      A[p] = m;
+      *reinterpret_cast<vec_t*>(dp + ((long)b * hw + p) * a.dst_ld[st] + a.dst_choff[st] + cc * CE) = m;
+    }
+    __syncthreads();
+  }
+}
+
 // fp8: 16 channels per thread; e4m3 bytes are compared through their float values (the byte patterns are sign-magnitude,
 // not two's complement) and the winning BYTE is kept, so the result is exact; the slice keeps its producer's scale.
 template <>

@@ -89,6 +89,7 @@ struct miyolo_engine {
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
   std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
+  int sppf_fuse = 1;        // three chained MAXPOOL5 ops (SPPF) as one launch (sppf3_kernel)
   int fuse_pre = 0;         // set by miyolo_detect around run_ops: the decode op also runs the NMS score filter
   int fuse_pre_opt = 1;     // option "fuse_prefilter"
   float fuse_conf = 0.f;
@@ -597,6 +598,32 @@ void build_lanes(miyolo_engine* h) {
   }
 }
 
+// ops i, i+1, i+2 = SPPF's pool chain (each pools the previous one's output, same width, same map)?  Then one launch.
+template <typename T>
+bool try_sppf3(miyolo_engine* h, int i, int last, const Plan& p, const void* in, void* ws, hipStream_t s) {
+  constexpr int CE = DT<T>::CE;
+  if (!h->sppf_fuse || i + 2 >= last) return false;
+  const miyolo_op* o = &h->ops[i];
+  for (int k = 0; k < 3; ++k) if (o[k].kind != MIYOLO_OP_MAXPOOL5) return false;
+  auto same = [](const miyolo_view& a, const miyolo_view& b) { return a.buf == b.buf && a.ch_off == b.ch_off && a.ch_cnt == b.ch_cnt; };
+  if (!same(o[1].src[0], o[0].dst) || !same(o[2].src[0], o[1].dst) || o[0].src[0].ch_cnt != o[0].dst.ch_cnt) return false;
+  const miyolo_buf& sb = h->bufs[o[0].src[0].buf];
+  Sppf3Args a;
+  a.src = buf_ptr(h, p, o[0].src[0].buf, in, ws);
+  a.src_ld = sb.channels; a.src_choff = o[0].src[0].ch_off; a.ch = o[0].src[0].ch_cnt;
+  a.B = p.B; a.H = p.H / sb.down; a.W = p.W / sb.down;
+  if (a.ch % CE || a.src_choff % CE || a.src_ld % CE) return false;
+  for (int k = 0; k < 3; ++k) {
+    const miyolo_buf& ob = h->bufs[o[k].dst.buf];
+    if (ob.down != sb.down || o[k].dst.ch_off % CE || ob.channels % CE) return false;
+    a.dst[k] = buf_ptr(h, p, o[k].dst.buf, in, ws); a.dst_ld[k] = ob.channels; a.dst_choff[k] = o[k].dst.ch_off;
+  }
+  const size_t lds = (size_t)2 * a.H * a.W * 16;
+  if (lds > 64 * 1024) return false;
+  hipLaunchKernelGGL(sppf3_kernel<T>, dim3((unsigned)(a.ch / CE), (unsigned)a.B), dim3(256), lds, s, a);
+  return true;
+}
+
 int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
             float* cls_logits, float* cls_probs, hipStream_t s) {
   const bool lanes = h->head_lanes && !h->profile && h->n_lanes > 1 && first == 0 && last == (int)h->ops.size();
@@ -626,11 +653,18 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
       HIP_TRY(h, hipEventCreate(&rec.e1));
       HIP_TRY(h, hipEventRecord(rec.e0, s));
     }
-    const int rc = (h->desc.dtype == MIYOLO_F8) ? run_op<fp8_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
+    int fusedn = 0;
+    if (h->ops[i].kind == MIYOLO_OP_MAXPOOL5 && h->desc.dtype != MIYOLO_F8 && i + 2 < last &&
+        (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_lane[i] == h->op_lane[i + 2] && h->op_waits[i + 1].empty() && h->op_waits[i + 2].empty())))
+      fusedn = ((h->desc.dtype == MIYOLO_F16) ? try_sppf3<half_t>(h, i, last, p, in, ws, si) : try_sppf3<float>(h, i, last, p, in, ws, si)) ? 2 : 0;
+    const int rc = fusedn ? 0
+                   : (h->desc.dtype == MIYOLO_F8) ? run_op<fp8_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
                    : (h->desc.dtype == MIYOLO_F16)
                        ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
                        : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si);
     if (rc) return rc;
+    for (int k = 0; k < fusedn; ++k, ++i)                  // the two absorbed pools: same lane, their events mean the same launch
+      if (lanes && h->op_signal[i]) HIP_TRY(h, hipEventRecord(h->op_ev[i], si));
     if (lanes && h->op_signal[i]) HIP_TRY(h, hipEventRecord(h->op_ev[i], si));
     if (h->profile) {
       HIP_TRY(h, hipEventRecord(rec.e1, s));
@@ -997,6 +1031,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "head_lanes")) { h->head_lanes = value; return 0; }
   if (!strcmp(key, "nms_async")) { h->nms_async = value; return 0; }
   if (!strcmp(key, "fuse_prefilter")) { h->fuse_pre_opt = value; return 0; }
+  if (!strcmp(key, "sppf_fuse")) { h->sppf_fuse = value; return 0; }
   if (!strcmp(key, "batch_split")) { h->batch_split = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }

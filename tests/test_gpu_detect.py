@@ -407,3 +407,18 @@ def test_async_nms_pipelines_calls_without_changing_results():
     assert torch.equal(d2, ref["a"][0]) and torch.equal(c2, ref["a"][1])
     eng.wait_outputs()
     assert torch.equal(slots[1][0], ref["b"][0])
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_sppf_pools_as_one_launch_change_no_bit(dtype):
+    """SPPF's three chained MaxPool2d(5,1,2) (reference: ultralytics SPPF.forward) run as one launch (sppf3_kernel: separable
+    row / column max through LDS).  Max is exact: the head output equals the three-launch path bit for bit, on square and
+    non-square maps."""
+    sd, meta = synth_state_dict("detect", NC, "n", 0, nc_quirk=False), synth_meta("detect", NC, "n", False)
+    eng = engine_from_weights(sd, meta, dtype, 0, bgr_input=False)
+    for H, W in ((320, 320), (352, 608)):
+        frames = torch.from_numpy(synth_frames(3, H, W, seed=13, kind="noise")).cuda()
+        eng.set_option("sppf_fuse", 0)
+        y0 = eng.head_raw(frames).clone()
+        eng.set_option("sppf_fuse", 1)
+        assert torch.equal(eng.head_raw(frames), y0)
