@@ -74,17 +74,27 @@ struct MegaStream {
 };
 constexpr uint32_t kMegaOob = 0x80000000u;  // offset past any weight tensor: the load returns zeros
 
-// Fill of ring slot U.  M0 (the LDS base of an LDS-DMA) is the SAME value for every fill of a wave; the slot is chosen by
+// Fill of ring slot U.  M0 (the LDS base of an LDS-DMA) is the SAME value for every ring fill of a wave; the slot is chosen by
 // the instruction's 12-bit offset, which the hardware adds to the LDS address AND to the memory address - the descriptors
-// therefore start kMegaBack bytes early and the lane offset carries kMegaBack - 1024 U.  Why: with M0 rewritten per fill,
-// fills issued a few instructions apart (the ring's refill-only visits) landed in the wrong slot once the caches were warm
-// - 20-40 % of the images of every launch after the first; 16 idle cycles after each fill hid it, 4 did not, stricter
-// vmcnt waits did not.  A queued LDS-DMA evidently samples M0 after later SALU writes can reach it; nothing may depend on
-// how long that window is, so M0 never changes while fills are in flight.
+// therefore start kMegaBack bytes early and the lane offset carries kMegaBack - 1024 U (4 slots of 1 KiB = what one M0
+// reaches).  What is established about this stream's hazards, by replay against the layered path (tools/stress_cls_mega.py):
+//   * an 8-slot ring with M0 rewritten per fill gave wrong logits on 20-40 % of the images of every launch after the first
+//     (warm caches); 16 idle cycles after each fill hid it, 4 did not, stricter vmcnt waits did not;
+//   * this form - one M0 for the ring, at most two refill-only visits in a row, the bias fill with its own M0 between two
+//     32-cycle pauses - is clean over 6.6 x 10^5 images (batches 1...1024, 400 replays each);
+//   * a variant that made the bias a ring entry (one M0 for everything, but up to four refill-only visits in a row) failed
+//     again (18-63 images in 5 x 10^5), with or without the wait-state guard below.
+// The common factor is fills issued back to back with nothing but their address arithmetic in between; whether the LDS
+// base, the address register or the fill's completion count is what goes wrong there is NOT established.  The conv
+// kernels issue their fills in bursts too (each with its own M0) and have never differed in a replay
+// (tests/test_gpu_fullsize.py replays them); the tests keep both under watch.
 constexpr uint32_t kMegaBack = (kMegaPf - 1) * 1024;
 template <int U>
 __device__ __forceinline__ void mega_load(uint32_t ring, const v4i_t rs, uint32_t off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%3 lds"
+  // s_nop 4: the descriptor or the ring address may have been written by a VALU op (v_readlane reloading a spilled SGPR)
+  // in the instruction before this statement; a VMEM op needs 5 wait states behind that, and the compiler's hazard pass
+  // does not look inside asm
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%3 lds"
                :: "s"(ring), "v"(off + (kMegaBack - U * 1024)), "s"(rs), "n"(U * 1024) : "memory", "m0");
 }
 __device__ __forceinline__ v4i_t mega_srd(const void* p, uint32_t bytes) {

@@ -38,7 +38,11 @@ __device__ __forceinline__ void lds_dma16(const v4i_t rsrc, uint32_t lds_addr, u
   const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
   const v4i_t rs = {__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]),
                     __builtin_amdgcn_readfirstlane(rsrc[2]), __builtin_amdgcn_readfirstlane(rsrc[3])};   // folded away when already in SGPRs
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+  // s_nop 2 (+ the two instructions behind it = 5 wait states): an operand SGPR may have been written by a VALU op right
+  // before this statement (v_readlane reloading a spilled SGPR, v_readfirstlane above when it is not folded away); a VMEM op
+  // needs 5 wait states behind such a write and the compiler's hazard pass does not look inside asm.  A scan of the
+  // generated code found 4 such places (spill reloads in conv_dmap<*,1,2,6>) among 3 420 DMA statements.
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
 }
 // The 4-byte form (lane l lands at lds_addr + 4*l): used to touch cache lines (L2 warm-up), the data is never read.
@@ -46,7 +50,7 @@ __device__ __forceinline__ void lds_dma4(const v4i_t rsrc, uint32_t lds_addr, ui
   const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
   const v4i_t rs = {__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]),
                     __builtin_amdgcn_readfirstlane(rsrc[2]), __builtin_amdgcn_readfirstlane(rsrc[3])};
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+  asm volatile("s_nop 2\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
                :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
 }
 __device__ __forceinline__ v4i_t make_srd(const void* p, uint32_t bytes) {

@@ -425,9 +425,11 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       } else {
       if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
       // narrow layers: the 2-D-tile kernel where there is a residual (it reads it under its K loop), the halo-slab kernel
-      // where there is none (f16; per-layer A/B at 48 channels, 160 x 160: 162 vs 182 us without, 220 / 183 vs 199 / 167 us with)
+      // where there is none (f16, detect models only: the classifier's layered path stays on the kernels whose K order the
+      // one-launch classifier reproduces bit for bit; per-layer A/B at 48 channels, 160 x 160: 162 vs 182 us without,
+      // 220 / 183 vs 199 / 167 us with)
       else if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0 &&
-                                     !(sizeof(T) == 2 && !a.res && h->h2 && h2_eligible<T>(a, 0.01 * h->h2_min_util)))) && t2d_eligible<T>(a))
+                                     !(sizeof(T) == 2 && !a.res && h->desc.task == 0 && h->h2 && h2_eligible<T>(a, 0.01 * h->h2_min_util)))) && t2d_eligible<T>(a))
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
       else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
 #if MIYOLO_EXPERIMENTS
@@ -516,7 +518,7 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
                    h->desc.dtype != MIYOLO_F8 &&
                    t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
   const bool s1 = op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample && ob.dtype != MIYOLO_F32 && op.cout % 8 == 0;
-  const bool h2_first = h->desc.dtype == MIYOLO_F16 && op.res.buf < 0;      // as run_op: narrow layers without a residual
+  const bool h2_first = h->desc.dtype == MIYOLO_F16 && op.res.buf < 0 && h->desc.task == 0;   // as run_op: narrow layers without a residual
   if (s1 && (h->conv_impl == 8 || (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && (!t2d || h2_first)))) {
     H2Geom hg; size_t hl; int hgeo;
     const int es = h->desc.dtype == MIYOLO_F16 ? 2 : h->desc.dtype == MIYOLO_F8 ? 1 : 4, tc = h2_pick_tc(op.cout, es);
