@@ -80,8 +80,9 @@ constexpr uint32_t kMegaOob = 0x80000000u;  // offset past any weight tensor: th
 // reaches).  What is established about this stream's hazards, by replay against the layered path (tools/stress_cls_mega.py):
 //   * an 8-slot ring with M0 rewritten per fill gave wrong logits on 20-40 % of the images of every launch after the first
 //     (warm caches); 16 idle cycles after each fill hid it, 4 did not, stricter vmcnt waits did not;
-//   * this form - one M0 for the ring, at most two refill-only visits in a row, the bias fill with its own M0 between two
-//     32-cycle pauses - is clean over 6.6 x 10^5 images (batches 1...1024, 400 replays each);
+//   * this form - one M0 for the ring, at most two refill-only visits in a row and those (and the four fills of a stream
+//     start) kept 32 cycles apart, the bias fill with its own M0 between two 32-cycle pauses - is clean over 1.3 x 10^6
+//     images (batches 1...1024, 400 replays each, with and without the 32-cycle spacing);
 //   * a variant that made the bias a ring entry (one M0 for everything, but up to four refill-only visits in a row) failed
 //     again (18-63 images in 5 x 10^5), with or without the wait-state guard below.
 // The common factor is fills issued back to back with nothing but their address arithmetic in between; whether the LDS
@@ -130,8 +131,11 @@ __device__ __forceinline__ MegaStream mega_first_item(const MegaOp& nx, bool has
 __device__ __forceinline__ void mega_prefetch(const MegaStream& st, uint32_t ring, uint32_t bslot) {
   mega_load_bias(bslot, ring, st.rsb, st.boff);
   mega_load<0>(ring, st.rs, (0 < st.nsteps) ? st.arow : kMegaOob);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                  // fills 32 cycles apart, as in the refill-only visits
   mega_load<1>(ring, st.rs, (1 < st.nsteps) ? st.arow + 1024u : kMegaOob);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   mega_load<2>(ring, st.rs, (2 < st.nsteps) ? st.arow + 2048u : kMegaOob);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   mega_load<3>(ring, st.rs, (3 < st.nsteps) ? st.arow + 3072u : kMegaOob);
   static_assert(kMegaPf == 4, "one M0 reaches 4 KiB of LDS");
 }
@@ -248,6 +252,9 @@ __device__ __forceinline__ void mega_visit(const MegaItem& it, const unsigned ch
   const bool cur = t < it.nsteps;
   const uint32_t off = cur ? it.arow + (uint32_t)(t * 1024) : ((U < it.nsteps_n) ? it.arow_n + (uint32_t)(U * 1024) : kMegaOob);
   mega_load<U>(ring, cur ? it.rsw : it.rs_n, off);
+  // a refill-only visit has nothing between its fill and the next one: keep them 32 cycles apart (the only mitigation the
+  // experiments above support; two such visits per item, next to an epilogue of ~1.5 k cycles)
+  if (U >= NU) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
 
 // One turn of the ring: slots 0..NU-1 hold K steps k0..k0+NU-1 of the item and are consumed; every slot is then refilled
