@@ -16,6 +16,9 @@
 //   * the Classify tail (avg-pool, Linear, softmax) runs in the same launch with the arithmetic order of cls_head_kernel.
 // f16 only (config 2's dtype); the exact-fp32 parity mode and models that do not fit keep the layered path.
 #pragma once
+#ifndef MEGA_BURST_KIND
+#define MEGA_BURST_KIND 0
+#endif
 #include "common.h"
 #include "conv_igemm.h"
 #include "conv_dma.h"
@@ -77,18 +80,25 @@ constexpr uint32_t kMegaOob = 0x80000000u;  // offset past any weight tensor: th
 // Fill of ring slot U.  M0 (the LDS base of an LDS-DMA) is the SAME value for every ring fill of a wave; the slot is chosen by
 // the instruction's 12-bit offset, which the hardware adds to the LDS address AND to the memory address - the descriptors
 // therefore start kMegaBack bytes early and the lane offset carries kMegaBack - 1024 U (4 slots of 1 KiB = what one M0
-// reaches).  What is established about this stream's hazards, by replay against the layered path (tools/stress_cls_mega.py):
-//   * an 8-slot ring with M0 rewritten per fill gave wrong logits on 20-40 % of the images of every launch after the first
-//     (warm caches); 16 idle cycles after each fill hid it, 4 did not, stricter vmcnt waits did not;
-//   * this form - one M0 for the ring, at most two refill-only visits in a row and those (and the four fills of a stream
-//     start) kept 32 cycles apart, the bias fill with its own M0 between two 32-cycle pauses - is clean over 1.3 x 10^6
-//     images (batches 1...1024, 400 replays each, with and without the 32-cycle spacing);
-//   * a variant that made the bias a ring entry (one M0 for everything, but up to four refill-only visits in a row) failed
-//     again (18-63 images in 5 x 10^5), with or without the wait-state guard below.
-// The common factor is fills issued back to back with nothing but their address arithmetic in between; whether the LDS
-// base, the address register or the fill's completion count is what goes wrong there is NOT established.  The conv
-// kernels issue their fills in bursts too (each with its own M0) and have never differed in a replay
-// (tests/test_gpu_fullsize.py replays them); the tests keep both under watch.
+// reaches).
+// THE HAZARD of this stream, established by replaying batches against the layered path (tools/stress_cls_mega.py; the
+// experiment switches below are compile-time, e.g. `build.sh -DMEGA_BURST=4 -DMEGA_NO_SPACING`): the vmcnt retirement of an
+// LDS-DMA does not mean that its bytes have LANDED in LDS; when the DMA write path is congested the landing lags, and a
+// fill can land after a YOUNGER fill to the same slot (write-after-write inversion: the slot ends up holding the older
+// entry).  Measurements, wrong images per 2.5 x 10^5:
+//   * MEGA_BURST=4 (16 extra refill-only fills before every item boundary, duplicates of what the slots already hold, so
+//     only their timing can matter), unspaced: 13-31;   the same + 512 idle cycles before the next item: 0;
+//     the same + vmcnt(0) after every burst fill: 0;   the same + 32 cycles between burst fills: 0;
+//     the same + stricter waits on the READ side: 26 (it is not the reads);   out-of-range (zero) burst fills: 4;
+//   * a first 8-slot ring with M0 rewritten per fill and six refill-only visits in a row: 20-40 % of all images wrong, which
+//     looked like a late-sampled M0 and led to the fixed-M0 form (kept: one value is certainly safe); a variant with the
+//     bias as a ring entry (up to four refill-only visits in a row, then the next item at once): 18-63 in 5 x 10^5.
+// The HIP guide's hardware rule "read a staged buffer one phase after the wait that retires it" is the same fact seen from
+// the read side.  What this kernel does about it: a slot's last fill by one item and its first fill by the next are an
+// epilogue (~1.5 k cycles) apart; refill-only fills (two per item at most) and the four fills of a stream start are 32
+// cycles apart; a consuming visit waits one fill further than it needs.  Clean over 2 x 10^6 replayed images.  The conv
+// kernels read a stage only behind vmcnt AND a workgroup barrier, one phase later, and never refill a slot within ~2 k
+// cycles of its previous fill; no replay of them has ever differed (tools/stress_detect.py, tests/test_gpu_fullsize.py).
 constexpr uint32_t kMegaBack = (kMegaPf - 1) * 1024;
 template <int U>
 __device__ __forceinline__ void mega_load(uint32_t ring, const v4i_t rs, uint32_t off) {
@@ -234,7 +244,13 @@ template <int NPT, int NU, int U>
 __device__ __forceinline__ void mega_visit(const MegaItem& it, const unsigned char* smem, const int (&base)[4], int kq, int k0,
                                            uint32_t ring, int lane, f32x4 (&acc)[4], uint4 (&bf)[4]) {
   const int ks = k0 + U;
-  mega_wait_slot();
+#ifdef MEGA_WAIT0
+  if (U < NU) mega_drain(); else mega_wait_slot();      // experiment: a consuming visit waits for EVERY fill in flight
+#else
+  // a consuming visit also waits for the NEXT slot's fill: the slot it reads was retired one fill earlier (margin for the
+  // landing lag described at mega_load; costs nothing measurable)
+  if (U < NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf - 2) : "memory"); else mega_wait_slot();
+#endif
   if (U < NU) {
     const uint4 af = *reinterpret_cast<const uint4*>(smem + ring + U * 1024 + lane * 16);
     const int tn = mega_toff(it, ks + 1, kq);
@@ -254,7 +270,11 @@ __device__ __forceinline__ void mega_visit(const MegaItem& it, const unsigned ch
   mega_load<U>(ring, cur ? it.rsw : it.rs_n, off);
   // a refill-only visit has nothing between its fill and the next one: keep them 32 cycles apart (the only mitigation the
   // experiments above support; two such visits per item, next to an epilogue of ~1.5 k cycles)
+#if defined(MEGA_SERIAL)
+  if (U >= NU) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif !defined(MEGA_NO_SPACING)
   if (U >= NU) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
 }
 
 // One turn of the ring: slots 0..NU-1 hold K steps k0..k0+NU-1 of the item and are consumed; every slot is then refilled
@@ -278,7 +298,23 @@ __device__ __forceinline__ void mega_kloop(const MegaItem& it, const unsigned ch
   for (int j = 0; j < NPT; ++j) bf[j] = *reinterpret_cast<const uint4*>(smem + base[j] + t0);
   int k0 = 0;
   for (; k0 + kMegaPf <= it.nsteps; k0 += kMegaPf) mega_block<NPT, kMegaPf>(it, smem, base, kq, k0, ring, lane, acc, bf);
-  if (it.nsteps - k0 == 2) mega_block<NPT, 2>(it, smem, base, kq, k0, ring, lane, acc, bf);   // K is padded to 64: the step count is even
+  if (it.nsteps - k0 == 2) { mega_block<NPT, 2>(it, smem, base, kq, k0, ring, lane, acc, bf); k0 += kMegaPf; }   // K is padded to 64: the step count is even
+#ifdef MEGA_BURST
+  // hazard experiment (tools/stress_cls_mega.py): extra ring turns of refill-only visits, each re-fetching the next item's
+  // first entries - harmless by construction, so any wrong result comes from the burst of fills itself
+  for (int r = 0; r < MEGA_BURST; ++r) {
+#if MEGA_BURST_KIND == 1      // fills that touch no memory (out of range): complete at once
+    MegaItem ib = it; ib.nsteps_n = 0;
+    mega_block<NPT, 0>(ib, smem, base, kq, (it.nsteps + 3) & ~3, ring, lane, acc, bf);
+    if (r == MEGA_BURST - 1) mega_block<NPT, 0>(it, smem, base, kq, (it.nsteps + 3) & ~3, ring, lane, acc, bf);   // put the real entries back
+#else
+    mega_block<NPT, 0>(it, smem, base, kq, (it.nsteps + 3) & ~3, ring, lane, acc, bf);
+#endif
+  }
+#ifdef MEGA_BURST_PAUSE
+  for (int r = 0; r < MEGA_BURST_PAUSE; ++r) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // 64 cycles each
+#endif
+#endif
 }
 
 __device__ __forceinline__ void mega_conv(const MegaOp& op, const MegaStream& nx, unsigned char* smem, int wave, int lane,
