@@ -120,8 +120,9 @@ int miyolo_k_align(int dtype);
 
 /* Replaces: YOLO(path) model construction + AutoBackend(fuse=True) (detect.py:20-21).
  * `weights[i]` are device pointers; conv weights are BN-folded, laid out [cout][kpad]
- * (see miyolo_k_align) in `desc->dtype`; biases fp32 [cout] zero padded to a multiple of 128
- * floats; the stem weight is [cout][32] in
+ * (see miyolo_k_align) in `desc->dtype`; biases (and the F8 qscale / bias_init arrays) fp32 [cout] zero padded to a
+ * multiple of 128 floats (the kernels fetch them 16 at a time through the scalar cache, which is not range-checked; the
+ * host side of this repository adds 256 floats of slack on top); the stem weight is [cout][32] in
  * `desc->dtype`, K' = 8q+j with q<3: (ky=q, byte j = kx*3+c, j<8), q=3: j<3 -> (ky=j,kx=2,c=2),
  * rest zero; the 1/255 input scale is NOT folded (the kernel divides the uint8 pixel by 255 as
  * the reference's preprocess does); CLS_HEAD weight fp32 [nc][c]. */
@@ -207,7 +208,9 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * the first conv and the box / class branches behind it - on internal side streams, forked and joined by events around
  * the caller's stream; 0: everything in order on the caller's stream; same kernels, same results), "fuse_prefilter" (1
  * default: miyolo_detect's decode kernel also runs the NMS score filter; 0: separate pass; same results), "sppf_fuse" (1
- * default: three chained MAXPOOL5 ops run as one launch; same results), "batch_split" (0 default;
+ * default: three chained MAXPOOL5 ops run as one launch; same results), "bneck_fuse" (1 default: in F16 a narrow Bottleneck -
+ * conv3x3, conv3x3 + residual of the first one's input, 16 / 32 / 48 channels, the intermediate read by nobody else - runs
+ * as one launch with the intermediate tile in LDS; same results as the two launches on the 2-D-tile kernel), "batch_split" (0 default;
  * K > 1: a batch that fits one pass runs as K part batches on K streams when the workspace holds K part plans - measured
  * +0.8..1.4 % on configuration 1, left off), "cls_streams" (1 default:
  * > 1 makes miyolo_classify fork the batch over that many internal streams, joined by events - measured slower), and the

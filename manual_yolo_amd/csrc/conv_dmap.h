@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       const int nt = __builtin_amdgcn_readfirstlane(e_n0 + (wc * TC + i) * 16);
       const int n = nt + fq * 4;
       v4i_t s0, s1, s2, s3;
-      const float* bp = sgpr_ptr(a.bias + nt);
+      const float* bp = sgpr_ptr(a.bias + (nt < a.cout ? nt : 0));
       asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
                    "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
                    : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
@@ -516,8 +516,12 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
         for (int i = 0; i < TC; ++i) {
           const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + i) * 16);
           const int n = nt + fq * 4;
-          v4i_t s0, s1, s2, s3;            // 16 consecutive biases of this 16-channel tile, in SGPRs
-          const float* bp = sgpr_ptr(bias + nt);
+          // 16 consecutive biases of this 16-channel tile, in SGPRs.  A channel tile that lies wholly beyond cout (the last
+          // workgroup tile of e.g. 256 channels cut in 96s) loads tile 0 instead: scalar loads are not range-checked, and
+          // past the 128-float padding of the array they ran off its allocation - an intermittent memory access fault
+          // once a 256-channel layer existed (the fused Detect convs) and the array sat at the end of a mapped range
+          v4i_t s0, s1, s2, s3;
+          const float* bp = sgpr_ptr(bias + (nt < a.cout ? nt : 0));
           asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
                        "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
                        : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
             bv[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s1[r] : fq == 2 ? s2[r] : s3[r]);
           float sv[4] = {1.f, 1.f, 1.f, 1.f};
           if constexpr (is_fp8<T>::value) {        // per-output-channel dequantisation scale, same scalar-load route
-            const float* qp = sgpr_ptr(a.qscale + nt);
+            const float* qp = sgpr_ptr(a.qscale + (nt < a.cout ? nt : 0));
             asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
                          "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
                          : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(qp));

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
           const int nt = __builtin_amdgcn_readfirstlane(n0 + (cn * TC + i) * 16);
           const int n = nt + fq * 4;
           v4i_t s0, s1, s2, s3;
-          const float* bp = sgpr_ptr(bias + nt);
+          const float* bp = sgpr_ptr(bias + (nt < a.cout ? nt : 0));
           asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\t"
                        "s_load_dwordx4 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"
                        : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3) : "s"(bp));

@@ -33,6 +33,7 @@
 #endif
 #include "kernels_misc.h"
 #include "cls_mega.h"
+#include "conv_bneck.h"
 #include "nms.h"
 #include "preprocess.h"
 
@@ -89,6 +90,7 @@ struct miyolo_engine {
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
   std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
+  int bneck_fuse = 1;       // a narrow Bottleneck's two 3x3 convs as one launch (conv_bneck.h), f16
   int sppf_fuse = 1;        // three chained MAXPOOL5 ops (SPPF) as one launch (sppf3_kernel)
   int fuse_pre = 0;         // set by miyolo_detect around run_ops: the decode op also runs the NMS score filter
   int fuse_pre_opt = 1;     // option "fuse_prefilter"
@@ -630,6 +632,48 @@ bool try_sppf3(miyolo_engine* h, int i, int last, const Plan& p, const void* in,
   return true;
 }
 
+// ops i, i+1 = a narrow Bottleneck (conv3x3 -> conv3x3 + residual of the first one's input, C -> C -> C channels, the
+// intermediate buffer read by nobody else)?  Then one launch (conv_bneck.h).  f16 only.
+bool try_bneck(miyolo_engine* h, int i, int last, const Plan& p, const void* in, void* ws, hipStream_t s) {
+  if (!h->bneck_fuse || h->desc.dtype != MIYOLO_F16 || i + 1 >= last) return false;
+  const miyolo_op& o1 = h->ops[i];
+  const miyolo_op& o2 = h->ops[i + 1];
+  auto same = [](const miyolo_view& a, const miyolo_view& b) { return a.buf == b.buf && a.ch_off == b.ch_off && a.ch_cnt == b.ch_cnt; };
+  auto c3 = [](const miyolo_op& o) { return o.kind == MIYOLO_OP_CONV && o.ksize == 3 && o.stride == 1 && o.n_src == 1 && !o.src[0].upsample; };
+  if (!c3(o1) || !c3(o2) || o1.res.buf >= 0 || o2.res.buf < 0) return false;
+  const int C = o1.cin;
+  if (o1.cout != C || o2.cin != C || o2.cout != C) return false;
+  if (!same(o2.src[0], o1.dst) || !same(o2.res, o1.src[0]) || o1.src[0].buf <= 0) return false;
+  const miyolo_buf& xb = h->bufs[o1.src[0].buf];
+  const miyolo_buf& tb = h->bufs[o1.dst.buf];
+  const miyolo_buf& yb = h->bufs[o2.dst.buf];
+  if (xb.dtype != -1 || tb.dtype != -1 || yb.dtype != -1 || xb.down != tb.down || xb.down != yb.down) return false;
+  if (tb.channels != C || o1.dst.ch_off != 0) return false;                 // the intermediate owns its buffer ...
+  for (int k = 0; k < (int)h->ops.size(); ++k) {                            // ... and only the second conv reads it
+    if (k == i + 1) continue;
+    const miyolo_op& o = h->ops[k];
+    const int ns = o.kind == MIYOLO_OP_CONV ? o.n_src : o.kind == MIYOLO_OP_DECODE ? 3 : 1;
+    for (int q = 0; q < ns; ++q) if (o.src[q].buf == o1.dst.buf) return false;
+    if (o.kind == MIYOLO_OP_CONV && o.res.buf == o1.dst.buf) return false;
+    if (k != i && o.kind != MIYOLO_OP_DECODE && o.kind != MIYOLO_OP_CLS_HEAD && o.dst.buf == o1.dst.buf) return false;
+  }
+  const int H = p.H / xb.down, W = p.W / xb.down;
+  size_t lds;
+  if (!bneck_shape_ok(C, H, W, &lds)) return false;
+  if (xb.channels % 8 || o1.src[0].ch_off % 8 || yb.channels % 4 || o2.dst.ch_off % 4) return false;
+  const size_t xbytes = (size_t)p.B * H * W * xb.channels * 2, ybytes = (size_t)p.B * H * W * yb.channels * 2;
+  if (xbytes >= ((size_t)1 << 31) || ybytes >= ((size_t)1 << 31)) return false;
+  BneckArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = buf_ptr(h, p, o1.src[0].buf, in, ws); a.x_bytes = (uint32_t)xbytes; a.x_ld = xb.channels; a.x_choff = o1.src[0].ch_off;
+  a.dst = buf_ptr(h, p, o2.dst.buf, in, ws); a.dst_bytes = (uint32_t)ybytes; a.dst_ld = yb.channels; a.dst_choff = o2.dst.ch_off;
+  a.w1 = h->weights[o1.weight]; a.w2 = h->weights[o2.weight];
+  a.b1 = static_cast<const float*>(h->weights[o1.bias]); a.b2 = static_cast<const float*>(h->weights[o2.bias]);
+  a.kpad = (9 * C + 63) / 64 * 64;
+  a.B = p.B; a.H = H; a.W = W; a.act1 = o1.act; a.act2 = o2.act;
+  return launch_conv_bneck(a, C, s, h->ncu) == hipSuccess;
+}
+
 int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
             float* cls_logits, float* cls_probs, hipStream_t s) {
   const bool lanes = h->head_lanes && !h->profile && h->n_lanes > 1 && first == 0 && last == (int)h->ops.size();
@@ -660,7 +704,10 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
       HIP_TRY(h, hipEventRecord(rec.e0, s));
     }
     int fusedn = 0;
-    if (h->ops[i].kind == MIYOLO_OP_MAXPOOL5 && h->desc.dtype != MIYOLO_F8 && i + 2 < last &&
+    if (h->ops[i].kind == MIYOLO_OP_CONV && h->ops[i].ksize == 3 && i + 1 < last &&
+        (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) && try_bneck(h, i, last, p, in, ws, si))
+      fusedn = 1;
+    else if (h->ops[i].kind == MIYOLO_OP_MAXPOOL5 && h->desc.dtype != MIYOLO_F8 && i + 2 < last &&
         (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_lane[i] == h->op_lane[i + 2] && h->op_waits[i + 1].empty() && h->op_waits[i + 2].empty())))
       fusedn = ((h->desc.dtype == MIYOLO_F16) ? try_sppf3<half_t>(h, i, last, p, in, ws, si) : try_sppf3<float>(h, i, last, p, in, ws, si)) ? 2 : 0;
     const int rc = fusedn ? 0
@@ -953,6 +1000,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_h2_attrs<float>();
   if (e == hipSuccess) e = set_h2_attrs<half_t>();
   if (e == hipSuccess) e = set_h2_attrs<fp8_t>();
+  if (e == hipSuccess) e = set_bneck_attrs();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 3>();
   if (e == hipSuccess) e = set_t2d_attrs<float>();
@@ -1038,6 +1086,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "nms_async")) { h->nms_async = value; return 0; }
   if (!strcmp(key, "fuse_prefilter")) { h->fuse_pre_opt = value; return 0; }
   if (!strcmp(key, "sppf_fuse")) { h->sppf_fuse = value; return 0; }
+  if (!strcmp(key, "bneck_fuse")) { h->bneck_fuse = value; return 0; }
   if (!strcmp(key, "batch_split")) { h->batch_split = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }

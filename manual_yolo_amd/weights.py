@@ -66,8 +66,10 @@ def pack_stem_weight(wf: torch.Tensor, bgr_input: bool, dtype: str) -> torch.Ten
 
 
 def _pad128(v: torch.Tensor) -> torch.Tensor:
-    out = torch.zeros(((v.numel() + 127) // 128 * 128,), dtype=torch.float32)    # padded: the persistent conv kernel
-    out[:v.numel()] = v                                                        # s_loads 16 at a time
+    # padded: the conv kernels s_load 16 biases at a time (scalar loads are not range-checked).  A multiple of 128 covers
+    # every channel tile that starts below cout; the 256 floats on top are slack for any tile shape (include/miyolo.h)
+    out = torch.zeros(((v.numel() + 127) // 128 * 128 + 256,), dtype=torch.float32)
+    out[:v.numel()] = v
     return out
 
 

@@ -422,3 +422,22 @@ def test_sppf_pools_as_one_launch_change_no_bit(dtype):
         y0 = eng.head_raw(frames).clone()
         eng.set_option("sppf_fuse", 1)
         assert torch.equal(eng.head_raw(frames), y0)
+
+
+@pytest.mark.parametrize("scale,H,W", [("n", 320, 384), ("m", 640, 640), ("m", 256, 320)])
+def test_fused_bottleneck_changes_no_bit(scale, H, W):
+    """A narrow Bottleneck (reference: ultralytics Bottleneck.forward in C2f - x + cv2(cv1(x)), two 3x3 Conv+BN+SiLU) runs as
+    ONE launch in f16 (conv_bneck.h: both weight matrices and the intermediate tile in LDS).  Same K order, same f16 rounding
+    of the intermediate, same epilogue arithmetic: the head output must equal the two-launch path bit for bit, borders and
+    all (the intermediate is zero outside the image)."""
+    sd, meta = synth_state_dict("detect", NC, scale, 0, nc_quirk=False), synth_meta("detect", NC, scale, False)
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    frames = torch.from_numpy(synth_frames(3, H, W, seed=17, kind="blocks")).cuda()
+    # the two-launch reference with the halo-slab kernel off: that kernel sums K in another order (chunk, tap, channel),
+    # so with it the first conv of a narrow Bottleneck differs from the fused kernel's in the last bits
+    eng.set_option("h2", 0)
+    eng.set_option("bneck_fuse", 0)
+    y0 = eng.head_raw(frames).clone()
+    eng.set_option("bneck_fuse", 1)
+    y1 = eng.head_raw(frames)
+    assert torch.equal(y1, y0), f"max diff {float((y1 - y0).abs().max())}"
