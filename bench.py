@@ -224,6 +224,8 @@ def cpu_baseline(args, sd, meta, frames_np):
 def kernel_name(cfg, kind, dtype):
     if not cfg:
         return {0: "stem", 2: "maxpool5", 3: "decode", 4: "cls_head"}.get(kind, "op")
+    if cfg >= 9000:
+        return "conv_bneck<%s,tc%d>" % (dtype, cfg % 10)           # two 3x3 convs of a narrow Bottleneck in one launch
     fam = ("conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else
            "conv_halop" if cfg >= 4000 else "conv_dmap" if cfg >= 3000 else "conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm")
     return "%s<%s,k%d,wc%d,tc%d>" % (fam, dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)
@@ -239,9 +241,20 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
     eng.set_option("profile", 0)
     chunk = eng.chunk(B, H, W)
     per, perop = {}, {}
+    recorded = {op for op, _, _ in recs}
     for op, cfg, ms in recs:
         o = eng.prog.ops[op]
         fl, by = eng.op_work(op, min(chunk, B), H, W)
+        # ops absorbed into this launch (a fused Bottleneck's second conv, SPPF's 2nd and 3rd pool) have no record of their
+        # own: their algorithmic work belongs to it.  The intermediate of a fused Bottleneck never touches HBM: its bytes
+        # are not added (flops are)
+        nxt = op + 1
+        while nxt < len(eng.prog.ops) - 1 and nxt not in recorded and eng.prog.ops[nxt].kind in (1, 2):
+            f2, b2 = eng.op_work(nxt, min(chunk, B), H, W)
+            fl += f2
+            if cfg < 9000:
+                by += b2
+            nxt += 1
         e0 = perop.setdefault(op, {"name": o.name, "kind": o.kind, "k": o.ksize, "s": o.stride, "cin": o.cin, "cout": o.cout,
                                    "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl, "bytes": by})
         e0["n"] += 1; e0["ms"] += ms

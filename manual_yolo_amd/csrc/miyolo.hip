@@ -705,8 +705,10 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
     }
     int fusedn = 0;
     if (h->ops[i].kind == MIYOLO_OP_CONV && h->ops[i].ksize == 3 && i + 1 < last &&
-        (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) && try_bneck(h, i, last, p, in, ws, si))
+        (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) && try_bneck(h, i, last, p, in, ws, si)) {
       fusedn = 1;
+      rec.cfg = 9000 + 300 + h->ops[i].cout / 16;           // conv_bneck_kernel<TC>
+    }
     else if (h->ops[i].kind == MIYOLO_OP_MAXPOOL5 && h->desc.dtype != MIYOLO_F8 && i + 2 < last &&
         (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_lane[i] == h->op_lane[i + 2] && h->op_waits[i + 1].empty() && h->op_waits[i + 2].empty())))
       fusedn = ((h->desc.dtype == MIYOLO_F16) ? try_sppf3<half_t>(h, i, last, p, in, ws, si) : try_sppf3<float>(h, i, last, p, in, ws, si)) ? 2 : 0;
