@@ -7,7 +7,8 @@
 // (157 MB at batch 64) goes to HBM and comes back, as does the input a second time for the residual.  Here a persistent
 // workgroup keeps BOTH weight matrices in LDS (2 x 43 KiB), fetches the 20 x 20 input halo tile once, computes the 18 x 18
 // intermediate tile into LDS (zero outside the image: the second conv's padding), computes the 16 x 16 output tile from
-// it, adds the residual from the input tile it still holds, and stores: 38 KB in + 24 KB out per tile instead of 135 KB.
+// it, adds the residual (read from the input tile into registers before the next tile's fetch overwrites it), and stores:
+// 38 KB in + 24 KB out per tile instead of 135 KB; the next tile's halo tile flies under the second conv.
 // Same MFMA, same flattened K order (tap, channel), same f16 rounding of the intermediate, same epilogue arithmetic as
 // the two-launch path (conv_t2d.h / conv_dmap.h): results are bit-identical to it (tests/test_gpu_conv.py).
 // LDS (C = 48): w1, w2 [48][912 B] | tap tables | X 20x20 px x 96 B (+ the tail of its last DMA) | T 18x18 px x 96 B = 156 KiB.
@@ -123,23 +124,30 @@ __global__ __launch_bounds__(512) void conv_bneck_kernel(const BneckArgs a) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) baseB[j] = ((2 * wave + j) * kBnT + frow) * XROW;
 
-  __syncthreads();
-  int tile = first;
-  for (int t = 0; t < my_tiles; ++t, tile += Gd) {
+  auto tile_coords = [&](int tile, int* b, int* ty, int* tx) {
     const uint32_t bb = magic_div((uint32_t)tile, a.mg_img_mul, a.mg_img_shift);
     const uint32_t r = (uint32_t)tile - bb * (uint32_t)(a.tiles_x * a.tiles_y);
-    const int ty = (int)magic_div(r, a.mg_tx_mul, a.mg_tx_shift), tx = (int)r - ty * a.tiles_x, b = (int)bb;
-    // ---- X: 20 x 20 halo tile, zeros outside the image (out-of-range DMA offsets)
-    {
-      const int32_t origin = ((b * a.H + ty * 16) * a.W + tx * 16) * ldB + a.x_choff * 2;
-      const uint32_t st = lds_base + (uint32_t)(G::X_OFF + wave * NDW * 1024);
+    *ty = (int)magic_div(r, a.mg_tx_mul, a.mg_tx_shift); *tx = (int)r - *ty * a.tiles_x; *b = (int)bb;
+  };
+  // X: the 20 x 20 halo tile of `tile`, zeros outside the image (out-of-range DMA offsets)
+  auto issue_x = [&](int tile) {
+    int b, ty, tx;
+    tile_coords(tile, &b, &ty, &tx);
+    const int32_t origin = ((b * a.H + ty * 16) * a.W + tx * 16) * ldB + a.x_choff * 2;
+    const uint32_t st = lds_base + (uint32_t)(G::X_OFF + wave * NDW * 1024);
 #pragma unroll
-      for (int d = 0; d < NDW; ++d) {
-        const int gy = ty * 16 - 2 + hy[d], gx = tx * 16 - 2 + hx[d];
-        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        lds_dma16(rsx, st + d * 1024, ok ? (uint32_t)(origin + rel[d]) : 0x80000000u);
-      }
+    for (int d = 0; d < NDW; ++d) {
+      const int gy = ty * 16 - 2 + hy[d], gx = tx * 16 - 2 + hx[d];
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      lds_dma16(rsx, st + d * 1024, ok ? (uint32_t)(origin + rel[d]) : 0x80000000u);
     }
+  };
+  __syncthreads();
+  issue_x(first);
+  int tile = first;
+  for (int t = 0; t < my_tiles; ++t, tile += Gd) {
+    int b, ty, tx;
+    tile_coords(tile, &b, &ty, &tx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- conv A -> T (18 x 18, SiLU, f16, zero outside the image)
@@ -183,8 +191,18 @@ __global__ __launch_bounds__(512) void conv_bneck_kernel(const BneckArgs a) {
         }
       }
     }
-    __syncthreads();
-    // ---- conv B -> output tile, + residual (the input tile's centre), store
+    // the residual operand of this wave's output pixels (the input tile's centre) goes to registers now, so that the X
+    // buffer is free behind the barrier below and the NEXT tile's halo tile can fly under conv B and its epilogue
+    f16x4 resv[TC][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char* xr = xl + ((2 * wave + j + 2) * kBnX + frow + 2) * XROW;
+#pragma unroll
+      for (int i = 0; i < TC; ++i) resv[i][j] = *reinterpret_cast<const f16x4*>(xr + (i * 16 + fq * 4) * 2);
+    }
+    __syncthreads();                                         // T complete; nobody reads X any more
+    if (t + 1 < my_tiles) issue_x(tile + Gd);
+    // ---- conv B -> output tile, + residual, store
     {
       f32x4 acc[TC][2];
 #pragma unroll
@@ -208,11 +226,10 @@ __global__ __launch_bounds__(512) void conv_bneck_kernel(const BneckArgs a) {
       for (int j = 0; j < 2; ++j) {
         const int oy = 2 * wave + j;
         const int m = (b * a.H + ty * 16 + oy) * a.W + tx * 16 + frow;
-        const unsigned char* xr = xl + ((oy + 2) * kBnX + frow + 2) * XROW;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
           const int n = i * 16 + fq * 4;
-          const f16x4 h = *reinterpret_cast<const f16x4*>(xr + n * 2);
+          const f16x4 h = resv[i][j];
           float v[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_bneck_kernel(const BneckArgs a) {
         }
       }
     }
-    __syncthreads();                                         // X (residual) and T are free again
+    // the barrier at the top of the next tile (behind its X wait) also says that everybody is done with T
   }
 }
 
