@@ -202,7 +202,8 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * 2-D-tile kernel), "dmh_auto" (0 default: conv_impl 3 hands launches with 1-2 tiles per CU to
  * kernel 6), "ncu" (width of the persistent grids, default = the device's CU count), "graph"
  * (1: detect/classify calls are captured into a hipGraph and replayed while shape, thresholds,
- * stream and pointers stay the same; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
+ * stream and pointers stay the same - from the SECOND call with that key on: the first runs directly; the head chains stay on
+ * the caller's stream while this option is on; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
  * "h2_min_util" percent (70) of the map; "h2_warm" = 1 selects its persistent form), "cls_mega" (1 default: an f16 classifier whose activations fit LDS runs as ONE launch, cls_mega.h; 0: one launch per
  * layer; bit-identical results), "head_lanes" (1 default: detect runs the Detect head's independent conv chains - per level
  * the first conv and the box / class branches behind it - on internal side streams, forked and joined by events around

@@ -2,6 +2,8 @@
 
 Detection parity is UNPINNED by the reference (poker_model.pt is absent): these tests pin the
 HIP path to the oracle on seeded synthetic weights."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -441,3 +443,22 @@ def test_fused_bottleneck_changes_no_bit(scale, H, W):
     eng.set_option("bneck_fuse", 1)
     y1 = eng.head_raw(frames)
     assert torch.equal(y1, y0), f"max diff {float((y1 - y0).abs().max())}"
+
+
+def test_detect_hip_graph_replay():
+    """Option graph: a detect call - the fused launches and the NMS included; the head chains stay on the caller's stream
+    under capture - is captured once and replayed; results equal the direct launches, call after call, and a new input
+    pointer re-captures."""
+    sd, meta = synth_state_dict("detect", NC, "n", 0, nc_quirk=False), synth_meta("detect", NC, "n", False)
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    fa = torch.from_numpy(synth_frames(4, 320, 320, seed=31, kind="noise")).cuda()
+    fb = torch.from_numpy(synth_frames(4, 320, 320, seed=32, kind="blocks")).cuda()
+    ref = {k: [t.clone() for t in eng.detect(f, conf=0.25, iou=0.7)] for k, f in (("a", fa), ("b", fb))}
+    eng.set_option("graph", 1)
+    out = tuple(torch.empty_like(t) for t in ref["a"])
+    for i in range(6):
+        k, f = ("a", fa) if i % 3 else ("b", fb)
+        eng.detect(f, conf=0.25, iou=0.7, out=out)
+        torch.cuda.synchronize()
+        for got, want in zip(out, ref[k]):
+            assert torch.equal(got, want), f"call {i}"
