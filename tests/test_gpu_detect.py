@@ -462,3 +462,18 @@ def test_detect_hip_graph_replay():
         torch.cuda.synchronize()
         for got, want in zip(out, ref[k]):
             assert torch.equal(got, want), f"call {i}"
+
+
+def test_batch_split_runs_part_batches_beside_each_other_unchanged():
+    """Option batch_split = K: a batch that fits one pass runs as K part batches on K streams (each with its own slice of the
+    workspace); frames are independent, so detections must equal the single-pass ones exactly."""
+    sd, meta = synth_state_dict("detect", NC, "n", 0, nc_quirk=False), synth_meta("detect", NC, "n", False)
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    frames = torch.from_numpy(synth_frames(8, 320, 384, seed=41, kind="blocks")).cuda()
+    ref = [t.clone() for t in eng.detect(frames, conf=0.05, iou=0.7)]
+    assert int(ref[1].sum()) > 0
+    for k in (2, 4):
+        eng.set_option("batch_split", k)
+        for _ in range(3):
+            got = eng.detect(frames, conf=0.05, iou=0.7)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), f"batch_split {k}"
