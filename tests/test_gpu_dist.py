@@ -40,11 +40,35 @@ def test_fused_gather_over_rccl_overlaps_and_matches(nccl_world1):
     for k, f in enumerate(frames):                 # batch k+1 is enqueued while gather k runs on the side stream
         if k >= 2:
             got.append(tuple(t.clone() for t in g.wait(k - 2)))      # slot about to be overwritten
-        eng.detect(f, want_anchor=False, out=g.out_buffers(k))
-        g.launch(k)
+        # exactly bench.py's step: deferred wait, the gather's side stream waits for the detections by itself
+        eng.detect(f, want_anchor=False, out=g.out_buffers(k), defer=True)
+        g.launch(k, ready=eng.wait_outputs)
     for k in range(max(0, len(frames) - 2), len(frames)):
         got.append(tuple(t.clone() for t in g.wait(k)))
     torch.cuda.synchronize()
     for (wd, wc), (gd, gc) in zip(want, got):
         assert torch.equal(wd, gd) and torch.equal(wc, gc)
         assert sum(len(x) for x in unpad(gd.cpu(), gc.cpu())) == int(gc.sum())
+
+
+def test_gather_behind_an_asynchronous_nms(nccl_world1):
+    """Option nms_async: the detections of a call are produced on the library's internal stream; the gather's side stream must
+    wait for them through the `ready` hook (Engine.wait_outputs) - the payload it sends is then the finished one."""
+    sd, meta = synth_state_dict("detect", 64, "n", 0), synth_meta("detect", 64, "n")
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    B, max_det = 4, 300
+    frames = [torch.from_numpy(synth_frames(B, 160, 160, seed=s)).cuda() for s in (5, 6, 7, 8)]
+    want = [tuple(t.clone() for t in eng.detect(f, conf=0.05, want_anchor=False)[:2]) for f in frames]
+    eng.set_option("nms_async", 1)
+    g = DetectionGather(B, max_det, "cuda:0", depth=2, always_collective=True)
+    got = []
+    for k, f in enumerate(frames):
+        if k >= 2:
+            got.append(tuple(t.clone() for t in g.wait(k - 2)))
+        eng.detect(f, conf=0.05, want_anchor=False, out=g.out_buffers(k), defer=True)
+        g.launch(k, ready=eng.wait_outputs)
+    for k in range(len(frames) - 2, len(frames)):
+        got.append(tuple(t.clone() for t in g.wait(k)))
+    torch.cuda.synchronize()
+    for (wd, wc), (gd, gc) in zip(want, got):
+        assert torch.equal(wd, gd) and torch.equal(wc, gc)
