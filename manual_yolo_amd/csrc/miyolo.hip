@@ -34,6 +34,7 @@
 #include "kernels_misc.h"
 #include "cls_mega.h"
 #include "conv_bneck.h"
+#include "conv_stem2.h"
 #include "nms.h"
 #include "preprocess.h"
 
@@ -91,6 +92,7 @@ struct miyolo_engine {
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
   std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
+  int stem_fuse = 0;        // the stem and the first stride-2 conv as one launch (conv_stem2.h), f16: measured no gain, off
   int bneck_fuse = 1;       // a narrow Bottleneck's two 3x3 convs as one launch (conv_bneck.h), f16
   int sppf_fuse = 1;        // three chained MAXPOOL5 ops (SPPF) as one launch (sppf3_kernel)
   int fuse_pre = 0;         // set by miyolo_detect around run_ops: the decode op also runs the NMS score filter
@@ -633,6 +635,39 @@ bool try_sppf3(miyolo_engine* h, int i, int last, const Plan& p, const void* in,
   return true;
 }
 
+// ops i (the stem) and i+1 (conv3x3 stride 2 on the stem's output, which nobody else reads)?  Then one launch (conv_stem2.h).
+bool try_stem2(miyolo_engine* h, int i, int last, const Plan& p, const void* in, void* ws, hipStream_t s) {
+  if (!h->stem_fuse || h->desc.dtype != MIYOLO_F16 || i + 1 >= last) return false;
+  const miyolo_op& o0 = h->ops[i];
+  const miyolo_op& o1 = h->ops[i + 1];
+  if (o0.kind != MIYOLO_OP_STEM || o1.kind != MIYOLO_OP_CONV || o1.ksize != 3 || o1.stride != 2 || o1.n_src != 1 || o1.src[0].upsample || o1.res.buf >= 0) return false;
+  const miyolo_buf& sb = h->bufs[o0.dst.buf];
+  const miyolo_buf& yb = h->bufs[o1.dst.buf];
+  if (sb.dtype != -1 || yb.dtype != -1 || sb.down != 2 || yb.down != 4 || sb.channels != o0.cout || o0.dst.ch_off != 0) return false;
+  if (o1.src[0].buf != o0.dst.buf || o1.src[0].ch_off != 0 || o1.src[0].ch_cnt != o0.cout || o1.cin != o0.cout) return false;
+  for (int k = 0; k < (int)h->ops.size(); ++k) {            // the stem's map is read by layer 1 only
+    if (k == i + 1) continue;
+    const miyolo_op& o = h->ops[k];
+    const int ns = o.kind == MIYOLO_OP_CONV ? o.n_src : o.kind == MIYOLO_OP_DECODE ? 3 : 1;
+    if (o.kind != MIYOLO_OP_STEM) for (int q = 0; q < ns; ++q) if (o.src[q].buf == o0.dst.buf) return false;
+    if (o.kind == MIYOLO_OP_CONV && o.res.buf == o0.dst.buf) return false;
+  }
+  size_t lds;
+  if (!stem2_shape_ok(o0.cout, o1.cout, p.H, p.W, &lds)) return false;
+  if (yb.channels % 4 || o1.dst.ch_off % 4) return false;
+  const size_t inb = (size_t)p.B * p.H * p.W * 3, yb_bytes = (size_t)p.B * (p.H / 4) * (p.W / 4) * yb.channels * 2;
+  if (inb >= ((size_t)1 << 31) || yb_bytes >= ((size_t)1 << 31)) return false;
+  Stem2Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = static_cast<const uint8_t*>(in); a.in_bytes = (uint32_t)inb;
+  a.w0 = h->weights[o0.weight]; a.b0 = static_cast<const float*>(h->weights[o0.bias]);
+  a.w1 = h->weights[o1.weight]; a.b1 = static_cast<const float*>(h->weights[o1.bias]);
+  a.dst = buf_ptr(h, p, o1.dst.buf, in, ws); a.dst_bytes = (uint32_t)yb_bytes; a.dst_ld = yb.channels; a.dst_choff = o1.dst.ch_off;
+  a.kpad = (9 * o0.cout + 63) / 64 * 64;
+  a.B = p.B; a.H = p.H; a.W = p.W; a.act0 = o0.act; a.act1 = o1.act;
+  return launch_conv_stem2(a, o0.cout, o1.cout, s, h->ncu) == hipSuccess;
+}
+
 // ops i, i+1 = a narrow Bottleneck (conv3x3 -> conv3x3 + residual of the first one's input, C -> C -> C channels, the
 // intermediate buffer read by nobody else)?  Then one launch (conv_bneck.h).  f16 only.
 bool try_bneck(miyolo_engine* h, int i, int last, const Plan& p, const void* in, void* ws, hipStream_t s) {
@@ -707,7 +742,11 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
       HIP_TRY(h, hipEventRecord(rec.e0, s));
     }
     int fusedn = 0;
-    if (h->ops[i].kind == MIYOLO_OP_CONV && h->ops[i].ksize == 3 && i + 1 < last &&
+    if (h->ops[i].kind == MIYOLO_OP_STEM && i + 1 < last && (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) &&
+        try_stem2(h, i, last, p, in, ws, si)) {
+      fusedn = 1;
+      rec.cfg = 9000 + 400 + h->ops[i + 1].cout / 16;        // conv_stem2_kernel
+    } else if (h->ops[i].kind == MIYOLO_OP_CONV && h->ops[i].ksize == 3 && i + 1 < last &&
         (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) && try_bneck(h, i, last, p, in, ws, si)) {
       fusedn = 1;
       rec.cfg = 9000 + 300 + h->ops[i].cout / 16;           // conv_bneck_kernel<TC>
@@ -1018,6 +1057,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_h2_attrs<half_t>();
   if (e == hipSuccess) e = set_h2_attrs<fp8_t>();
   if (e == hipSuccess) e = set_bneck_attrs();
+  if (e == hipSuccess) e = set_stem2_attrs();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 3>();
   if (e == hipSuccess) e = set_t2d_attrs<float>();
@@ -1104,6 +1144,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "fuse_prefilter")) { h->fuse_pre_opt = value; return 0; }
   if (!strcmp(key, "sppf_fuse")) { h->sppf_fuse = value; return 0; }
   if (!strcmp(key, "bneck_fuse")) { h->bneck_fuse = value; return 0; }
+  if (!strcmp(key, "stem_fuse")) { h->stem_fuse = value; return 0; }
   if (!strcmp(key, "batch_split")) { h->batch_split = value; return 0; }
   if (!strcmp(key, "cls_streams")) { if (value < 1 || value > 16) return fail(h, MIYOLO_ERR_ARG, "cls_streams out of range"); h->cls_streams = value; return 0; }
   if (!strcmp(key, "h2_warm")) { h->h2_warm = value; return 0; }

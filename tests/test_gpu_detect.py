@@ -477,3 +477,19 @@ def test_batch_split_runs_part_batches_beside_each_other_unchanged():
         for _ in range(3):
             got = eng.detect(frames, conf=0.05, iou=0.7)
             assert all(torch.equal(a, b) for a, b in zip(got, ref)), f"batch_split {k}"
+
+
+@pytest.mark.parametrize("scale,H,W", [("n", 320, 384), ("m", 640, 640), ("m", 256, 320), ("m", 352, 608)])
+def test_fused_stem_and_first_conv_change_no_bit(scale, H, W):
+    """The stem and layer 1 (reference: DetectionModel layers 0 and 1, both Conv 3x3 stride 2 + BN + SiLU) run as ONE launch
+    in f16 (conv_stem2.h: layer 1's weights and the patch of the stem's output it needs in LDS, the stem's map never written).
+    Same arithmetic as stem_kernel followed by the ring kernel: the head output equals the two-launch path bit for bit,
+    image borders included; frames whose quarter-resolution width is not a multiple of 16 keep the two launches."""
+    sd, meta = synth_state_dict("detect", NC, scale, 0, nc_quirk=False), synth_meta("detect", NC, scale, False)
+    eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
+    frames = torch.from_numpy(synth_frames(3, H, W, seed=23, kind="blocks")).cuda()
+    eng.set_option("stem_fuse", 0)
+    y0 = eng.head_raw(frames).clone()
+    eng.set_option("stem_fuse", 1)
+    y1 = eng.head_raw(frames)
+    assert torch.equal(y1, y0), f"max diff {float((y1 - y0).abs().max())}"
