@@ -52,32 +52,84 @@ def parse():
     ap.add_argument("--parity-frames", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=50.0)
     ap.add_argument("--profile-out", default="")
+    ap.add_argument("--force-spawn", action="store_true", help="take the self-spawn path (one child per rank) even for --gpus 1")
     return ap.parse_args()
 
 
-def spawn_ranks(args):
+def visible_gpus():
+    """GPUs this process may use, WITHOUT touching the HIP/HSA runtime (an exec from a GPU-initialised process is fatal on this
+    pool, and `torch.cuda.device_count()` falls through to hipGetDeviceCount on ROCm): the kfd topology in sysfs lists one
+    node per agent, GPUs are the nodes with a non-zero `simd_count`; HIP_/ROCR_VISIBLE_DEVICES narrow it.  None: unknown."""
+    import glob
+    n = 0
+    try:
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except (OSError, ValueError):
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def spawn_ranks(args, timeout_s=1500.0):
     """`python bench.py --gpus N` without torchrun: start one child per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set),
-    relay rank 0's JSON line, fail if any rank fails.  The parent never initialises the GPU."""
+    relay rank 0's JSON line, fail if any rank fails.  The parent imports neither torch nor the package and makes no HIP
+    call (GPU count from sysfs); it polls ALL children: the first non-zero exit or the overall timeout ends the others (a
+    rank that died would otherwise leave rank 0 waiting in the collective for ever)."""
     import socket
-    import torch
+    import tempfile
     n = args.gpus
-    have = torch.cuda.device_count()          # does not initialise the runtime
-    if have < n and not os.environ.get("MIYOLO_FORCE_DEVICE"):
+    have = visible_gpus()
+    if have is not None and have < n and not os.environ.get("MIYOLO_FORCE_DEVICE"):
         print(f"[bench] --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    argv = [a for a in sys.argv[1:] if a != "--force-spawn"]
+    procs, outs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else None
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out if r == 0 else subprocess.DEVNULL, text=True))
+    t_end = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > t_end:
+            failed = "timed out after %.0f s (ranks still running: %s)" % (timeout_s, [r for r, rc in enumerate(rcs) if rc is None])
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:                      # exactly the children started above, by PID
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"[bench] {failed}", file=sys.stderr)
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read())
     sys.stdout.flush()
-    return 0 if all(rc == 0 for rc in rcs) else 1
+    return 1 if failed else 0
 
 
 # ----------------------------------------------------------------------------------------------- parity vs the oracle
@@ -319,7 +371,7 @@ def model_roofline(eng, B, H, W, dtype, ms_per_step):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_spawn) and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     import numpy as np  # noqa: F401
     import torch

@@ -284,6 +284,23 @@ int miyolo_merge_slices(miyolo_handle h, const float* dets, const int32_t* count
                         int H, int W, float iou, int agnostic, int max_det, float* y_scratch, float* out_dets, int32_t* out_counts,
                         int32_t* out_index, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The merge step as the reference's call reaches it: pipe.py:186-188 calls [3P] sahi.get_sliced_prediction WITHOUT any
+ * postprocess_* argument, i.e. with sahi's defaults - postprocess_type "GREEDYNMM", match metric "IOS", threshold 0.5,
+ * class-aware.  Candidates = the per-slice detections (layout as for miyolo_merge_slices; a full-frame pass is passed as
+ * one more "slice" at origin (0, 0) LAST, as sahi appends it), shifted into frame coordinates, clipped to frame_w x
+ * frame_h, degenerate boxes dropped.  Per class (all together if `agnostic`): in descending score order a candidate
+ * still in the pool becomes a keep and removes every later candidate whose inter / min(area) (metric 0 = IOS) or IoU
+ * (metric 1) is not below `threshold` (fp32, as torch); then each keep absorbs its matched candidates in score order,
+ * each only if it still matches the keep's grown box (metric > threshold, fp64, as numpy): box = hull, score and class =
+ * the keep's.  Restated in oracle/post_ref.py greedy_nmm_merge; kept-set, boxes and order identical
+ * (tests/test_gpu_sahi.py).  out_dets [max_out][6] rows x1,y1,x2,y2,score,cls by descending score (ties: sahi's output
+ * order), zero padded; out_counts [2] = rows written, merged boxes in total (or -n when more than 4096 candidates came
+ * in: nothing written); out_index (optional) [max_out] the keep's candidate slot slice * slice_max_det + row.
+ * Stateless; errors through miyolo_last_error(NULL).  Asynchronous on `stream`. */
+int miyolo_merge_slices_nmm(const float* dets, const int32_t* counts, const int32_t* boxes, int n_slices, int slice_max_det,
+                            int frame_h, int frame_w, int metric, float threshold, int agnostic, int max_out, float* out_dets,
+                            int32_t* out_counts, int32_t* out_index, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

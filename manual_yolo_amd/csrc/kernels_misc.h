@@ -377,7 +377,11 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const ClsHeadArgs a) {
   const T* f = reinterpret_cast<const T*>(a.feat) + (long)b * a.hw * a.c;
   for (int ch = threadIdx.x; ch < a.c; ch += 256) {
     float s = 0.f;
-    for (int p = 0; p < a.hw; ++p) s += (float)f[(long)p * a.c + ch];
+    for (int p = 0; p < a.hw; ++p) {
+      // fp8 features: the stored e4m3 values; their activation scale is folded into the Linear's columns by the host
+      if constexpr (is_fp8<T>::value) s += __builtin_amdgcn_cvt_f32_fp8((int)f[(long)p * a.c + ch].v, 0);
+      else s += (float)f[(long)p * a.c + ch];
+    }
     pooled[ch] = s / (float)a.hw;
   }
   __syncthreads();

@@ -37,6 +37,7 @@
 #include "conv_stem2.h"
 #include "nms.h"
 #include "preprocess.h"
+#include "nmm.h"
 
 using namespace miyolo;
 
@@ -111,6 +112,8 @@ struct miyolo_engine {
   std::vector<hipEvent_t> lane_ev;   // [0] fork, [1 + i] join of lane i
   uint32_t cls_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // `classes=` filter of the NMS prefilter (miyolo_set_classes)
   int use_cls_mask = 0;
+  std::vector<char> buf_stale;   // buffer never written under the current options (its producer runs inside a fused launch and
+                                 // keeps it in LDS): miyolo_read_buffer refuses it instead of returning uninitialised memory
   int profile = 0;          // 1: bracket every op launch with hipEvents (bench/roofline only)
   struct ProfRec { int op, cfg; hipEvent_t e0, e1; };
   std::vector<ProfRec> prof;
@@ -492,8 +495,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       break;
     }
     case MIYOLO_OP_CLS_HEAD: {
-      if constexpr (is_fp8<T>::value) return fail(h, MIYOLO_ERR_UNSUPPORTED, "classification is not built for fp8");
-      else {
+      {
       const miyolo_buf& sb = h->bufs[op.src[0].buf];
       ClsHeadArgs a;
       a.feat = buf_ptr(h, p, op.src[0].buf, in, ws);
@@ -760,6 +762,12 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
                        ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
                        : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si);
     if (rc) return rc;
+    if (h->ops[i].kind == MIYOLO_OP_STEM || h->ops[i].kind == MIYOLO_OP_CONV) {
+      // the stem+conv and Bottleneck fusions (one absorbed op) keep the FIRST op's output in LDS: that buffer is never written
+      const bool kept_in_lds = fusedn == 1;
+      h->buf_stale[h->ops[i].dst.buf] = kept_in_lds;
+      if (kept_in_lds) h->buf_stale[h->ops[i + 1].dst.buf] = 0;
+    }
     for (int k = 0; k < fusedn; ++k, ++i)                  // the two absorbed pools: same lane, their events mean the same launch
       if (lanes && h->op_signal[i]) HIP_TRY(h, hipEventRecord(h->op_ev[i], si));
     if (lanes && h->op_signal[i]) HIP_TRY(h, hipEventRecord(h->op_ev[i], si));
@@ -1011,6 +1019,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   h->bufs.assign(bufs, bufs + desc->n_bufs);
   h->ops.assign(ops, ops + desc->n_ops);
   h->weights.assign(weights, weights + desc->n_weights);
+  h->buf_stale.assign(h->bufs.size(), 0);
   for (const miyolo_buf& b : h->bufs)
     if (b.down < 1 || b.channels < 1) { delete h; return fail(nullptr, MIYOLO_ERR_ARG, "buffer with channels %d / down %d", b.channels, b.down); }
   for (const miyolo_op& op : h->ops) {
@@ -1349,6 +1358,7 @@ int miyolo_classify(miyolo_handle h, const uint8_t* in, int B, int H, int W, flo
       m.in = in; m.logits = logits; m.probs = probs; m.B = B; m.stamps = h->dbg;
       hipLaunchKernelGGL(cls_mega_kernel, dim3((unsigned)B), dim3(kMegaWaves * 64), h->mega_lds, s, m);
       HIP_TRY(h, hipGetLastError());
+      std::fill(h->buf_stale.begin(), h->buf_stale.end(), 1);      // every activation stayed in LDS
       return 0;
     }
   }
@@ -1421,6 +1431,9 @@ int miyolo_read_buffer(miyolo_handle h, int buf, int B, int H, int W, float* out
   long n = 0;
   if (int rc = debug_buf(h, buf, B, H, W, &n)) return rc;
   if (!out || !workspace) return fail(h, MIYOLO_ERR_ARG, "null argument");
+  if (h->buf_stale[buf])
+    return fail(h, MIYOLO_ERR_UNSUPPORTED, "buffer %d was not written by the last run: its producer ran inside a fused launch that keeps it in "
+                "LDS (options bneck_fuse / stem_fuse); switch the fusion off to tap it", buf);
   DevGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const void* src = static_cast<unsigned char*>(workspace) + h->plan.buf_off[buf];
@@ -1577,6 +1590,26 @@ int miyolo_merge_slices(miyolo_handle h, const float* dets, const int32_t* count
   HIP_TRY(h, hipGetLastError());
   // every candidate already passed its slice's confidence threshold: conf = 0 keeps all real ones (score > 0)
   return miyolo_nms(h, y_scratch, 1, cap, H, W, 0.0f, iou, agnostic, max_det, nullptr, out_dets, out_counts, out_index, workspace, workspace_bytes, stream);
+}
+
+int miyolo_merge_slices_nmm(const float* dets, const int32_t* counts, const int32_t* boxes, int n_slices, int slice_max_det, int frame_h,
+                            int frame_w, int metric, float threshold, int agnostic, int max_out, float* out_dets, int32_t* out_counts,
+                            int32_t* out_index, void* stream) {
+  if (!dets || !counts || !boxes || !out_dets || !out_counts || n_slices < 1 || n_slices > 250 || slice_max_det < 1 || frame_h < 1 ||
+      frame_w < 1 || max_out < 1 || (metric != 0 && metric != 1))
+    return fail(nullptr, MIYOLO_ERR_ARG, "merge_slices_nmm: bad arguments (1..250 slices, metric 0 = IOS / 1 = IOU)");
+  NmmArgs a;
+  a.dets = dets; a.counts = counts; a.boxes = boxes; a.ns = n_slices; a.max_det = slice_max_det; a.H = frame_h; a.W = frame_w;
+  a.metric = metric; a.agnostic = agnostic; a.max_out = max_out; a.thr = threshold;
+  a.out_dets = out_dets; a.out_count = out_counts; a.out_index = out_index;
+  {   // per device, idempotent, cheap next to the launch: no cached flag (no global state)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_nmm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNmmLds);
+    if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "merge_slices_nmm attribute: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(greedy_nmm_kernel, dim3(1), dim3(kNmmThreads), kNmmLds, static_cast<hipStream_t>(stream), a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(nullptr, MIYOLO_ERR_HIP, "merge_slices_nmm launch: %s", hipGetErrorString(e));
+  return 0;
 }
 
 int miyolo_crop_resize(const void* frame, int H, int W, const int32_t* boxes, int n, int size, int max_short, void* out, void* stream) {

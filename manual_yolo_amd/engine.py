@@ -78,6 +78,7 @@ SYMBOLS = {
     "miyolo_crop_resize": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "miyolo_slice_batch": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "miyolo_merge_slices": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "miyolo_merge_slices_nmm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -192,6 +193,7 @@ class Engine:
         if rc != 0:
             raise MiyoloError(f"miyolo_create failed ({rc}): {self.lib.miyolo_last_error(None).decode()}")
         self.h = h
+        self.options: Dict[str, int] = {}            # what set_option was called with (library defaults are not listed)
         self._ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ plumbing
@@ -212,6 +214,7 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self.lib.miyolo_set_option(self.h, key.encode(), int(value)), "miyolo_set_option")
+        self.options[key] = int(value)
         if key == "graph":
             # hipGraph replay (library option "graph"): capture needs a non-default stream, and the replayed launches
             # write to the buffers of the captured call - so graph mode owns a side stream and per-shape output buffers
@@ -321,10 +324,15 @@ class Engine:
         return dets, counts, anchor
 
     def detect_sliced(self, frame: torch.Tensor, boxes, slice_hw, conf: float = 0.25, iou: float = 0.7, agnostic: bool = False,
-                      max_det: int = 300, extra: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                      max_det: int = 300, extra: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                      merge: str = "GREEDYNMM", match_metric: str = "IOS", match_threshold: float = 0.5,
+                      merge_agnostic: Optional[bool] = None):
         """One frame uint8 [H,W,3] (device) cut into slices `boxes` (list of x1,y1,x2,y2) of canvas slice_hw, ONE batched
-        miyolo_detect, boxes shifted back and merged by the class-aware NMS (miyolo_merge_slices).  `extra`: optional
-        (dets [1,max_det,6] in frame coordinates, counts [1]) of a full-frame pass to merge in as one more "slice" at (0,0).
+        miyolo_detect, boxes shifted back and merged on the device: `merge="GREEDYNMM"` (sahi's default, what the reference's
+        call reaches: miyolo_merge_slices_nmm, `match_metric` IOS / IOU, `match_threshold`) or `merge="NMS"` (the class-aware
+        NMS of the per-frame post-process at `iou`, miyolo_merge_slices - limited to n_slices * max_det <= the anchors of one
+        slice, 8400 at 640 x 640).  `extra`: optional (dets [1,max_det,6] in frame coordinates, counts [1]) of a full-frame
+        pass, merged in as one more "slice" at (0,0) placed last, as sahi appends it.
         Returns (dets [max_det,6] frame coordinates, count, index [max_det] = slice * max_det + row of every kept box)."""
         if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3:
             raise MiyoloError("frame must be uint8 [H,W,3]")
@@ -342,6 +350,20 @@ class Engine:
             counts = torch.cat([counts, extra[1].to(self.device).reshape(1).to(torch.int32)])
             bx = torch.cat([bx, torch.zeros((1, 4), dtype=torch.int32, device=self.device)])
             n += 1
+        if merge.upper() == "GREEDYNMM":
+            od = torch.empty((max_det, 6), dtype=torch.float32, device=self.device)
+            oc = torch.empty((2,), dtype=torch.int32, device=self.device)
+            oi = torch.empty((max_det,), dtype=torch.int32, device=self.device)
+            metric = {"IOS": 0, "IOU": 1}[match_metric.upper()]
+            if self.lib.miyolo_merge_slices_nmm(dets.contiguous().data_ptr(), counts.contiguous().data_ptr(), bx.data_ptr(), n, max_det, H, W, metric,
+                                                float(np.float32(match_threshold)), int(agnostic if merge_agnostic is None else merge_agnostic), max_det, od.data_ptr(), oc.data_ptr(),
+                                                oi.data_ptr(), self._stream()):
+                raise MiyoloError(f"miyolo_merge_slices_nmm failed: {self.lib.miyolo_last_error(None).decode()}")
+            if int(oc[1]) < 0:
+                raise MiyoloError(f"{-int(oc[1])} slice detections exceed the 4096 candidates the device merge holds: raise conf or lower max_det")
+            return od, oc[0], oi
+        if merge.upper() != "NMS":
+            raise MiyoloError(f"unknown merge {merge!r} (GREEDYNMM or NMS)")
         ws = self.workspace(n if extra is None else n - 1, sh, sw)
         cap = n * max_det
         if cap > self.num_anchors(sh, sw):
@@ -380,12 +402,14 @@ class Engine:
         c, d, _ = self.prog.bufs[buf]
         return (B, H // d, W // d, c)
 
-    def read_buffer(self, buf: int, B: int, H: int, W: int) -> torch.Tensor:
+    def read_buffer(self, buf: int, B: int, H: int, W: int, raw: bool = False) -> torch.Tensor:
+        """fp32 copy of an activation buffer [B, H/down, W/down, channels].  fp8 engines: the real-valued activations
+        (stored e4m3 value x the buffer's scale), or with `raw` the stored e4m3 values themselves."""
         ws = self.workspace(B, H, W)
         out = torch.empty(self.buffer_shape(buf, B, H, W), dtype=torch.float32, device=self.device)
         self._check(self.lib.miyolo_read_buffer(self.h, buf, B, H, W, out.data_ptr(), ws.data_ptr(), self._stream()),
                     "miyolo_read_buffer")
-        if self.dtype == "f8" and buf in self.quant.buf_scale:       # stored e4m3 values -> real activations
+        if self.dtype == "f8" and buf in self.quant.buf_scale and not raw:       # stored e4m3 values -> real activations
             out *= torch.from_numpy(self.quant.buf_scale[buf]).to(self.device)
         return out
 
@@ -432,18 +456,17 @@ class Engine:
 
 def engine_from_weights(sd: Dict[str, torch.Tensor], meta: dict, dtype: str = "f16", device: Optional[int] = None,
                         bgr_input: bool = True, calib_frames: Optional[torch.Tensor] = None, quant=None,
-                        gain_fix: bool = True, fuse_head: bool = True) -> Engine:
-    """dtype "f8" (detect only): static e4m3 quantisation, calibrated on `calib_frames` (uint8 [N,H,W,3]; default: eight
-    seeded synthetic frames at the model's image size) through the f16 engine, followed by the per-op gain correction
-    of quant.gain_correction - see quant.py."""
+                        gain_fix: bool = False, fuse_head: bool = True, bias_correction: bool = True) -> Engine:
+    """dtype "f8": static e4m3 quantisation, calibrated on `calib_frames` (uint8 [N,H,W,3]; default: eight seeded synthetic
+    frames at the model's image size - pass real frames / crops for a trained model) through the f16 engine: activation
+    ranges and channel means, the latter for the bias correction of the weight rounding (quant.py).  `gain_fix` re-enables
+    round 2's fitted per-op gains (off: see quant.py for what they were compensating)."""
     # Detect's two first convs per level run as one (f16 / f32; the fp8 build keeps them apart: one activation scale per op)
     prog = build_program(meta["task"], meta["nc"], meta["scale"], meta.get("spec"), meta.get("nc_quirk", True),
                          fuse_head=(dtype != "f8") and fuse_head)
     if dtype != "f8":
         return Engine(prog, sd, meta["bn_eps"], dtype, device, bgr_input, quant)
     from .quant import calibrate, gain_correction
-    if meta["task"] != "detect":
-        raise MiyoloError("fp8 is built for the detect path only")
     if calib_frames is None:
         from .synth import synth_frames
         sz = int(meta.get("imgsz", 640))
@@ -451,8 +474,9 @@ def engine_from_weights(sd: Dict[str, torch.Tensor], meta: dict, dtype: str = "f
                                                         synth_frames(4, sz, sz, seed=102, kind="blocks")]))
     eng16 = Engine(prog, sd, meta["bn_eps"], "f16", device, bgr_input) if (quant is None or gain_fix) else None
     if quant is None:
-        quant = calibrate(prog, sd, meta["bn_eps"], calib_frames, device, bgr_input, eng16=eng16)
+        quant = calibrate(prog, sd, meta["bn_eps"], calib_frames, device, bgr_input, eng16=eng16, bias_correction=bias_correction)
     eng = Engine(prog, sd, meta["bn_eps"], "f8", device, bgr_input, quant)
+    eng.gains = {}
     if gain_fix:
         n = max(1, min(4, calib_frames.shape[0], eng.chunk(4, calib_frames.shape[1], calib_frames.shape[2])))
         eng.gains = gain_correction(eng, eng16, calib_frames[:n])

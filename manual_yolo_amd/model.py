@@ -84,10 +84,14 @@ class YOLO:
     def predict_sliced(self, source, slice_height: int = 640, slice_width: int = 640, overlap_height_ratio: float = 0.2,
                        overlap_width_ratio: float = 0.2, conf: Optional[float] = None, iou: float = 0.7, max_det: int = 300,
                        half: bool = False, agnostic_nms: bool = False, classes=None, perform_standard_pred: bool = True,
-                       imgsz=None) -> List[Results]:
-        """Sliced inference as the reference's ``run_sahi`` does it (``pipe.py:183-194``: 640 x 640 slices, 20 % overlap),
-        as ONE batched call: device-side slicing, one ``miyolo_detect`` over all slices, device-side merge (sahi.py).
-        ``perform_standard_pred`` (sahi's default): the full-frame prediction joins the candidates."""
+                       imgsz=None, postprocess_type: str = "GREEDYNMM", postprocess_match_metric: str = "IOS",
+                       postprocess_match_threshold: float = 0.5, postprocess_class_agnostic: bool = False) -> List[Results]:
+        """Sliced inference as the reference's ``run_sahi`` does it (``pipe.py:183-194``: 640 x 640 slices, 20 % overlap,
+        every other ``get_sliced_prediction`` argument at sahi's default), as ONE batched call: device-side slicing, one
+        ``miyolo_detect`` over all slices, device-side merge (sahi.py).  ``perform_standard_pred`` (sahi's default): the
+        full-frame prediction joins the candidates, last.  ``postprocess_*``: sahi's names and defaults - GREEDYNMM with
+        IOS 0.5, class-aware; ``postprocess_type="NMS"`` merges with the model's class-aware NMS at ``iou`` instead.
+        ``conf`` is the per-slice score threshold (sahi's ``AutoDetectionModel`` default is 0.3, Ultralytics' 0.25 is ours)."""
         from .sahi import slice_boxes
         if self.task != "detect":
             raise ValueError("sliced inference is a detection feature")
@@ -107,7 +111,9 @@ class YOLO:
                 scale = torch.tensor([scale_params(tuple(x.shape[1:3]), (H, W))], dtype=torch.float32, device=eng.device)
                 d0, c0, _ = eng.detect(x, conf, iou, agnostic_nms, max_det, scale, want_anchor=False)
                 extra = (d0, c0)
-            d, c, idx = eng.detect_sliced(torch.from_numpy(np.ascontiguousarray(f)), boxes, (sh, sw), conf, iou, agnostic_nms, max_det, extra)
+            d, c, idx = eng.detect_sliced(torch.from_numpy(np.ascontiguousarray(f)), boxes, (sh, sw), conf, iou, agnostic_nms, max_det, extra,
+                                          merge=postprocess_type, match_metric=postprocess_match_metric, match_threshold=postprocess_match_threshold,
+                                          merge_agnostic=postprocess_class_agnostic if postprocess_type.upper() == "GREEDYNMM" else None)
             n = int(c)
             out.append(Results(f, f"image{i}.jpg", self.names, boxes=d[:n].cpu().clone(), anchor_idx=idx[:n].cpu().clone()))
         return out

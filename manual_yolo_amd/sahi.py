@@ -5,9 +5,11 @@ objects (``pipe.py:43-45`` constants, ``pipe.py:183-194`` ``run_sahi`` -> [3P] `
 ``pipe.py:288-302`` the trigger).  ``sahi`` is not installed here and not vendored; this module restates the part of its
 published algorithm that shapes the work - the slice grid - and replaces its host loop of per-slice predictions by ONE
 batched ``miyolo_detect`` over all slices, with the merge done on the device by the same class-aware NMS as the per-frame
-post-process (``miyolo_merge_slices``).  [3P] sahi's default merge is "GREEDYNMM" (boxes with IoS > 0.5 are united);
-plain NMS at the model's IoU threshold is used here instead (sahi's ``postprocess_type="NMS"``): it keeps one of
-several duplicates from overlapping slices rather than their union - stated as a difference.
+batched ``miyolo_detect`` over all slices, with the merge done on the device.  The merge the reference's call reaches is
+[3P] sahi's default, "GREEDYNMM" with IOS 0.5, class-aware (``pipe.py:186-188`` passes no ``postprocess_*`` argument):
+``miyolo_merge_slices_nmm`` (csrc/nmm.h; restated in oracle/post_ref.py ``greedy_nmm_merge``), the default of
+``YOLO.predict_sliced`` since round 3.  ``postprocess_type="NMS"`` keeps round 2's merge by the model's class-aware NMS
+(``miyolo_merge_slices``).
 """
 from __future__ import annotations
 

@@ -26,7 +26,7 @@ from .arch import CLASSIFY_HIDDEN, REG_MAX, build_program
 
 # Mean of the Detect class-branch bias: with unit-ish logit spread (gains file) this lets a
 # few hundred anchors of a 640x640 frame clear conf 0.25 (checked by tools/calibrate_synth.py).
-DET_CLS_BIAS = -6.5
+DET_CLS_BIAS = -8.0
 
 _GAINS_OVERRIDE: Optional[dict] = None  # set by tools/calibrate_synth.py while it runs
 
@@ -41,15 +41,28 @@ def _load_gains() -> dict:
 
 
 def _gain(task, nc, scale, seed, prefix) -> float:
-    """Per-layer scalar gain (LSUV-style calibration, tools/calibrate_synth.py).  The table
-    was fitted for (detect, nc=64, m, seed 0); other configs reuse it by layer name, which
-    keeps activations bounded well enough for tests."""
+    """Per-layer scalar gain (LSUV-style calibration, tools/calibrate_synth.py: raw conv output std 4 since round 3 - the
+    unit-variance table of rounds 1-2, tools/synth_gains_r2.json, made the network amplify a 1 % amplitude change of its
+    input 40-50x in exact fp32, see the tool's docstring).  The table was fitted for (detect, nc=64, m, seed 0); other
+    configs reuse it by layer name, which keeps activations bounded well enough for tests."""
     if _GAINS_OVERRIDE is not None:
         return _GAINS_OVERRIDE.get(prefix, 1.0)
     g = _load_gains()
     if g and g.get("task") == task:
         return g["gains"].get(prefix, 1.0)
     return 1.0
+
+
+def _bias_shift(task, nc, scale, prefix):
+    """Per-class offset of a Detect class-branch bias that cancels the class logit's response to the mean activation
+    (tools/calibrate_synth.py); only for the configuration the table was fitted for."""
+    if _GAINS_OVERRIDE is not None:
+        return None
+    g = _load_gains()
+    if g and g.get("task") == task and g.get("nc") == nc and g.get("scale") == scale:
+        v = g.get("bias_shift", {}).get(prefix)
+        return None if v is None or len(v) != nc else torch.tensor(v, dtype=torch.float32)
+    return None
 
 
 def synth_frames(n: int, h: int, w: int, seed: int = 1, kind: str = "noise") -> np.ndarray:
@@ -109,6 +122,9 @@ def synth_state_dict(task: str, nc: int, scale: str, seed: int = 0, nc_quirk: bo
                 if is_cls:
                     b = torch.randn(op.cout, generator=_gen(seed, r.prefix + ".bias")) * 0.5
                     sd[r.prefix + ".bias"] = b + (DET_CLS_BIAS if calibrate else 0.0)
+                    sh = _bias_shift(task, nc, scale, r.prefix) if calibrate else None
+                    if sh is not None:
+                        sd[r.prefix + ".bias"] = sd[r.prefix + ".bias"] + sh
                 else:
                     sd[r.prefix + ".bias"] = torch.randn(op.cout, generator=_gen(seed, r.prefix + ".bias")) * 0.5 + 1.0
         elif r.kind == "linear":

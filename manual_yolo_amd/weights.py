@@ -83,6 +83,7 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
     ce = CHUNK_ELEMS[dtype]
     op_of_weight = {op.weight: (i, op) for i, op in enumerate(prog.ops) if op.weight >= 0}
     qscales: Dict[int, torch.Tensor] = {}
+    bias_shift: Dict[int, torch.Tensor] = {}
     for wi, r in enumerate(prog.weights):
         if r.kind in ("conv", "stem", "bias"):
             if r.prefix not in folded:
@@ -104,6 +105,10 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
                     q, qs = quantize_conv_weight(wf, s_in)
                     qscales[oi] = qs
                     out.append(q)
+                    if quant.buf_mean:                        # bias correction (quant.py): E[rounding error of W] . E[x]
+                        from .quant import weight_rounding_shift
+                        m_in = np.concatenate([quant.buf_mean[v.buf][v.ch_off:v.ch_off + v.ch_cnt] for v in op.src])
+                        bias_shift[oi] = weight_rounding_shift(wf, q, qs, s_in, m_in)
                 else:
                     out.append(pack_conv_weight(wf, dtype))
             elif r.kind == "stem":
@@ -111,7 +116,12 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
             else:
                 out.append(_pad128(bf))
         elif r.kind == "linear":
-            out.append(sd[r.prefix + ".weight"].float().contiguous())
+            lw = sd[r.prefix + ".weight"].float()
+            if dtype == "f8":                                 # the head pools the stored e4m3 values: their scale goes into the columns
+                _, hop = op_of_weight[wi]
+                v = hop.src[0]
+                lw = lw * torch.from_numpy(quant.buf_scale[v.buf][v.ch_off:v.ch_off + v.ch_cnt]).view(1, -1)
+            out.append(lw.contiguous())
         elif r.kind == "linear_bias":
             out.append(sd[r.prefix + ".bias"].float().contiguous())
         else:
@@ -121,6 +131,8 @@ def build_weight_tensors(prog: Program, sd: Dict[str, torch.Tensor], eps: float,
     extra = {}
     for oi, qs in qscales.items():
         op = prog.ops[oi]
+        if oi in bias_shift:
+            out[op.bias][:qs.numel()] -= bias_shift[oi]
         bias = out[op.bias][:qs.numel()]
         extra[oi] = (len(out), len(out) + 1)
         out.append(_pad128(qs))

@@ -156,3 +156,94 @@ def scale_boxes(img1_shape: Tuple[int, int], boxes: np.ndarray, img0_shape: Tupl
     boxes[:, 0] = boxes[:, 0].clip(0, img0_shape[1]); boxes[:, 1] = boxes[:, 1].clip(0, img0_shape[0])
     boxes[:, 2] = boxes[:, 2].clip(0, img0_shape[1]); boxes[:, 3] = boxes[:, 3].clip(0, img0_shape[0])
     return boxes
+
+
+# ----------------------------------------------------------------------------------------------- sahi GREEDYNMM
+def greedy_nmm(boxes: np.ndarray, scores: np.ndarray, match_metric: str = "IOS", match_threshold: float = 0.5):
+    """[3P] sahi.postprocess.combine.greedy_nmm (sahi @ 6455e84, reference requirements.txt:76; not vendored) - the
+    matching half of the "GREEDYNMM" post-process that ``get_sliced_prediction`` applies by default, i.e. what the
+    reference's ``run_sahi`` reaches (pipe.py:186-188 passes no postprocess_* argument: GREEDYNMM, IOS, 0.5, class-aware).
+
+    Candidates of ONE class: boxes [n,4] xyxy fp32, scores [n].  Repeatedly: take the highest-scoring candidate S still
+    in the pool, compare it with every other candidate T still in the pool - ``inter / min(area_T, area_S)`` (IOS) or
+    ``inter / (area_T - inter + area_S)`` (IOU), all in fp32 as torch computes it - and remove from the pool every T whose
+    metric is NOT ``< match_threshold`` (so equality and NaN match); they are listed under S in descending score order.
+    Returns ``{keep_index: [matched indices...]}`` in keep order (descending score).  Score ties: sahi sorts with
+    ``torch.argsort`` (order of equal scores unspecified); here equal scores keep the LOWER index first."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    x1, y1, x2, y2 = (boxes[:, k] for k in range(4))
+    areas = (x2 - x1) * (y2 - y1)
+    order = list(np.argsort(-scores, kind="stable"))          # descending; sahi pops from the end of an ascending sort
+    thr = np.float32(match_threshold)
+    zero = np.float32(0)
+    out = {}
+    with np.errstate(invalid="ignore", divide="ignore"):
+        while order:
+            i = order.pop(0)
+            if not order:
+                out[int(i)] = []
+                break
+            rest = np.asarray(order)
+            w = np.maximum(np.minimum(x2[rest], x2[i]) - np.maximum(x1[rest], x1[i]), zero)
+            h = np.maximum(np.minimum(y2[rest], y2[i]) - np.maximum(y1[rest], y1[i]), zero)
+            inter = w * h
+            if match_metric == "IOU":
+                val = inter / ((areas[rest] - inter) + areas[i])
+            elif match_metric == "IOS":
+                val = inter / np.minimum(areas[rest], areas[i])
+            else:
+                raise ValueError(match_metric)
+            unmatched = val < thr
+            out[int(i)] = [int(t) for t in rest[~unmatched]]
+            order = [int(t) for t in rest[unmatched]]
+    return out
+
+
+def _match_value64(a, b, match_metric: str) -> float:
+    """[3P] sahi.postprocess.utils.calculate_bbox_iou / calculate_bbox_ios on two xyxy boxes, in float64 as numpy
+    computes them from the predictions' python floats."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    area_a = (a[2] - a[0]) * (a[3] - a[1]); area_b = (b[2] - b[0]) * (b[3] - b[1])
+    wh = (np.minimum(a[2:], b[2:]) - np.maximum(a[:2], b[:2])).clip(min=0)
+    inter = wh[0] * wh[1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if match_metric == "IOU":
+            return float(inter / (area_a + area_b - inter))
+        return float(inter / np.minimum(area_a, area_b))
+
+
+def greedy_nmm_merge(dets: np.ndarray, match_metric: str = "IOS", match_threshold: float = 0.5,
+                     class_agnostic: bool = False):
+    """[3P] sahi.postprocess.combine.GreedyNMMPostprocess.__call__ (+ batched_greedy_nmm, has_match,
+    merge_object_prediction_pair): dets [n,6] rows ``x1,y1,x2,y2,score,cls`` (the shifted per-slice predictions followed by
+    the full-frame ones, in sahi's list order).  Per class (ascending class id; all together if ``class_agnostic``) run
+    ``greedy_nmm``; then every keep absorbs its matched candidates one by one in descending score order, each only if it
+    STILL matches the keep's current (already grown) box - ``metric > threshold`` strictly, in float64 - and absorbing
+    means: box = the smallest box containing both, score = the larger score, class = that of the higher-scoring one.  A
+    matched candidate that fails this second test is dropped without contributing.
+    Returns (merged [m,6] fp32 in sahi's output order: classes ascending, keeps by descending score; keep_index [m];
+    members: list of the absorbed candidate indices per output row)."""
+    dets = np.asarray(dets, dtype=np.float32).reshape(-1, 6)
+    n = dets.shape[0]
+    groups = [np.arange(n)] if class_agnostic else [np.nonzero(dets[:, 5] == c)[0] for c in np.unique(dets[:, 5])]
+    rows, keeps, members = [], [], []
+    for g in groups:
+        k2m = greedy_nmm(dets[g, :4], dets[g, 4], match_metric, match_threshold)
+        for ki, mlist in k2m.items():
+            keep = int(g[ki])
+            box = [float(v) for v in dets[keep, :4]]
+            score, cls = float(dets[keep, 4]), float(dets[keep, 5])
+            took = []
+            for mi in mlist:
+                m = int(g[mi])
+                if _match_value64(box, dets[m, :4], match_metric) > match_threshold:
+                    mb = dets[m, :4]
+                    box = [min(box[0], float(mb[0])), min(box[1], float(mb[1])), max(box[2], float(mb[2])), max(box[3], float(mb[3]))]
+                    if not (score > float(dets[m, 4])):         # get_merged_category: pred1 if pred1.score > pred2.score else pred2
+                        cls = float(dets[m, 5])
+                    score = max(score, float(dets[m, 4]))
+                    took.append(m)
+            rows.append(box + [score, cls]); keeps.append(keep); members.append(took)
+    merged = np.asarray(rows, dtype=np.float32).reshape(-1, 6)
+    return merged, np.asarray(keeps, dtype=np.int64), members

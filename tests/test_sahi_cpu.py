@@ -30,3 +30,25 @@ def test_every_pixel_covered_and_slices_inside():
 
 def test_small_frame_is_one_slice():
     assert slice_boxes(300, 500) == [(0, 0, 500, 300)]
+
+
+def test_greedy_nmm_oracle_known_cases():
+    """oracle/post_ref.py greedy_nmm_merge ([3P] sahi GREEDYNMM restated) on cases worked by hand."""
+    from oracle.post_ref import greedy_nmm_merge
+    d = np.array([
+        [0, 0, 10, 10, 0.9, 1],       # keep A
+        [2, 2, 8, 8, 0.8, 1],         # inside A: IOS 1 -> absorbed, hull unchanged
+        [5, 0, 15, 10, 0.7, 1],       # half of it inside A: IOS exactly 0.5 -> matched (not < 0.5) but NOT absorbed (not > 0.5): dropped
+        [9, 0, 19, 10, 0.6, 1],       # IOS 0.1 with A -> its own keep
+        [0, 0, 10, 10, 0.95, 2],      # other class: untouched by class 1
+        [100, 100, 110, 110, 0.5, 1],
+    ], np.float32)
+    m, k, mem = greedy_nmm_merge(d)
+    assert k.tolist() == [0, 3, 5, 4] and mem == [[1], [], [], []]
+    assert np.array_equal(m[0], d[0]) and np.array_equal(m[3], d[4])
+    # a chain: B overlaps A enough, C overlaps only the hull of A and B enough... but C must have MATCHED A in the first pass
+    d2 = np.array([[0, 0, 10, 10, 0.9, 0], [4, 0, 14, 10, 0.8, 0], [8, 0, 12, 10, 0.7, 0]], np.float32)
+    m2, k2, mem2 = greedy_nmm_merge(d2)          # IOS(A,B) = 0.6 absorbed -> hull [0,14]; IOS(A,C) = 20/40 = 0.5 matched; vs hull: 40/40 = 1 > 0.5 absorbed
+    assert k2.tolist() == [0] and mem2 == [[1, 2]] and m2[0, :4].tolist() == [0, 0, 14, 10] and m2[0, 4] == np.float32(0.9)
+    m3, k3, _ = greedy_nmm_merge(d, class_agnostic=True)
+    assert k3[0] == 4 and m3[0, 5] == 2           # agnostic: the 0.95 box of class 2 leads and absorbs class-1 boxes, keeping ITS class
