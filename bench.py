@@ -13,6 +13,7 @@ ONE JSON line (contract in the task statement) with
   parity        the timed dtype's detections against the CPU oracle on a sample of the bench frames
                 ("mAP delta vs CPU ref" of BASELINE.json's metric: oracle detections are the ground truth),
   exact_f32     a short timed loop of the exact-fp32 mode (the mode that meets north_star's identical-indices bar),
+  classify_config2  BASELINE config 2 (the rank classifier, batch 256, f16): images/s, launches, HBM roofline, 63/67 check,
   cpu_baseline  the CPU oracle (restated Ultralytics CPU path) timed on this host's cores, SURVEY.md 8d protocol.
 """
 import argparse
@@ -49,6 +50,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true")
+    ap.add_argument("--no-classify", action="store_true", help="skip the config-2 side block (classifier, batch 256)")
     ap.add_argument("--parity-frames", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=50.0)
     ap.add_argument("--profile-out", default="")
@@ -270,6 +272,47 @@ def cpu_baseline(args, sd, meta, frames_np):
     return {"value": big["value"], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": model,
             "sample": f"torch-CPU fp32 restatement incl. NMS on the same synthetic frames, median of >= 10 timed iterations after 3 warm-up "
                       f"(bounded by {args.cpu_seconds:.0f} s), per batch size", "by_batch": res}
+
+
+# ----------------------------------------------------------------------------------------------- config 2 beside the headline
+def classify_block(dev, local, steps=200):
+    """BASELINE.json config 2 (yolov8n-cls rank classifier, 64 x 64, batch 256, f16, 1 GPU) as a side block of the headline
+    line, outside its timed region: images/s, launches per call, the HBM roofline of SURVEY.md 8d (406 KB of compulsory
+    fp16 traffic per image -> 19.6 M images/s at 8 TB/s) and the reference's known answer on the 67 validation crops."""
+    import numpy as np
+    import torch
+    from manual_yolo_amd.ckpt import load_bundle
+    from manual_yolo_amd.engine import engine_from_weights
+    from manual_yolo_amd.synth import synth_frames
+    g = os.path.join(ROOT, "tests", "golden")
+    sd, meta = load_bundle(os.path.join(g, "rank_best.safetensors"))
+    eng = engine_from_weights(sd, meta, "f16", local, bgr_input=False)
+    B = 256
+    x = torch.from_numpy(synth_frames(B, 64, 64, seed=0)).to(dev)
+    for _ in range(10):
+        eng.classify(x)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.classify(x)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    launches, lds = eng.classify_launches(64, 64)
+    fl, by = eng.work(B, 64, 64)
+    val = np.load(os.path.join(g, "rank_valid.npz"))
+    _, p = eng.classify(torch.from_numpy(val["pre_u8"]).to(dev))
+    top1 = int((p.argmax(1).cpu().numpy() == val["labels"]).sum())
+    ips = B / ms * 1e3
+    return {"workload": "yolov8n-cls rank_classifier weights (reference best.pt), 64x64, batch 256, f16, inputs resident in HBM",
+            "value": round(ips, 1), "unit": "images/s", "ms_per_call": round(ms, 4), "steps": steps, "launches_per_call": launches,
+            "lds_bytes_per_image": lds, "gflop_per_image": round(fl / B / 1e9, 5), "algorithmic_kb_per_image": round(by / B / 1e3, 1),
+            "roofline": {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "algorithmic bytes (each layer's input once + output once + weights once) / wall time of the call; "
+                                 "the one-launch kernel keeps activations in LDS, so its real HBM traffic is the input + weights only"},
+            "top1_on_reference_valid_crops": f"{top1}/67", "reference_known_answer": "63/67 (runs/rank_classifier/results.csv:21)"}
 
 
 # ----------------------------------------------------------------------------------------------- roofline from engine events
@@ -496,6 +539,9 @@ def main():
             p32 = parity_block(e32, sd, meta, frames_np, min(args.parity_frames, 4))
             exact["parity"] = {k: p32[k] for k in ("frames", "map50_95_delta", "kept_index_agreement", "frames_with_identical_kept_indices", "max_box_px", "max_score")}
         del e32
+    cls2 = None
+    if rank == 0 and world == 1 and task == "detect" and not args.no_classify:
+        cls2 = classify_block(dev, local)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sd, meta, frames_np)
         cpu["gpu_over_cpu"] = round(value / cpu["value"], 1)
@@ -520,7 +566,7 @@ def main():
                        "model_t_min_ms": round(t_min_ms, 4), "model_roofline_frac": round(mfrac, 4),
                        "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
                        "per_rank_fps": [round(x, 1) for x in rank_fps]},
-            "roofline": roofline, "parity": parity, "exact_f32": exact, "cpu_baseline": cpu,
+            "roofline": roofline, "parity": parity, "exact_f32": exact, "classify_config2": cls2, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

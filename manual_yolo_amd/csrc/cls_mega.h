@@ -93,12 +93,26 @@ constexpr uint32_t kMegaOob = 0x80000000u;  // offset past any weight tensor: th
 //   * a first 8-slot ring with M0 rewritten per fill and six refill-only visits in a row: 20-40 % of all images wrong, which
 //     looked like a late-sampled M0 and led to the fixed-M0 form (kept: one value is certainly safe); a variant with the
 //     bias as a ring entry (up to four refill-only visits in a row, then the next item at once): 18-63 in 5 x 10^5.
-// The HIP guide's hardware rule "read a staged buffer one phase after the wait that retires it" is the same fact seen from
-// the read side.  What this kernel does about it: a slot's last fill by one item and its first fill by the next are an
-// epilogue (~1.5 k cycles) apart; refill-only fills (two per item at most) and the four fills of a stream start are 32
-// cycles apart; a consuming visit waits one fill further than it needs.  Clean over 2 x 10^6 replayed images.  The conv
-// kernels read a stage only behind vmcnt AND a workgroup barrier, one phase later, and never refill a slot within ~2 k
-// cycles of its previous fill; no replay of them has ever differed (tools/stress_detect.py, tests/test_gpu_fullsize.py).
+// WHAT THIS KERNEL DOES ABOUT IT (round 3: ordering rules, not cycle margins - VERDICT r2 item 4).  The experiments say
+// which orderings hold: a READ behind the wave's own covering vmcnt always saw its fill (no wrong result ever came from the
+// consuming visits, and stricter read-side waits changed nothing), whereas the retirement of a slot's previous fill did NOT
+// order the next fill of that slot behind it when no read lay between them (the bursts: every fill waited vmcnt(3), i.e. for
+// its slot's previous fill), and a complete drain, vmcnt(0), did.  So:
+//   R1  a slot is READ only by the wave that filled it, behind that wave's own counted `s_waitcnt vmcnt(N)` covering the
+//       fill (the ordering the hardware gives a wave over its own LDS-DMAs, MI355X_MICROARCH.md "Two waves per SIMD" item
+//       7); the wait covers one fill MORE than the slot's own, so the slot's fill is never the youngest retired one;
+//   R2  AT MOST ONE fill per slot is ever in flight: a slot is refilled either right behind a read of it that R1 ordered
+//       behind its previous fill (consuming visits: fill -> wait -> read -> MFMA -> refill), or - where there is no read,
+//       the refill-only visits at an item's end and the four fills that start a stream - behind `s_waitcnt vmcnt(0)`, i.e.
+//       with NOTHING in flight at all;
+//   R3  M0 (the LDS base of an LDS-DMA) is written in the same asm statement as the DMA that uses it, one wait state
+//       ahead (the ISA's M0-write -> LDS-DMA rule), and is read by the hardware at issue; the bias fill's excursion to its
+//       own M0 window begins and ends inside one statement, so no ring fill can issue under the bias' M0.  (The `s_nop 15`
+//       pairs around it are left from round 2 and are NOT what correctness rests on.)
+// Cost of R2's vmcnt(0) against round 2's 32-cycle spacing: see DESIGN.md 4.5 (same-box A/B).  tools/stress_cls_mega.py
+// replays batches against the layered path, also with the detect engine busy on another stream (--with-detect), which is
+// the situation of chain.py.  The conv kernels read a stage only behind vmcnt AND a workgroup barrier, one phase later, and
+// refill a slot only behind a barrier that follows its last read (one fill per slot in flight as well).
 constexpr uint32_t kMegaBack = (kMegaPf - 1) * 1024;
 template <int U>
 __device__ __forceinline__ void mega_load(uint32_t ring, const v4i_t rs, uint32_t off) {
@@ -139,13 +153,11 @@ __device__ __forceinline__ MegaStream mega_first_item(const MegaOp& nx, bool has
 
 // (re)start the stream: bias of the wave's first item of the next layer, then its first kMegaPf steps
 __device__ __forceinline__ void mega_prefetch(const MegaStream& st, uint32_t ring, uint32_t bslot) {
+  mega_drain();                                                       // R2: a stream starts with nothing in flight
   mega_load_bias(bslot, ring, st.rsb, st.boff);
   mega_load<0>(ring, st.rs, (0 < st.nsteps) ? st.arow : kMegaOob);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                  // fills 32 cycles apart, as in the refill-only visits
   mega_load<1>(ring, st.rs, (1 < st.nsteps) ? st.arow + 1024u : kMegaOob);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   mega_load<2>(ring, st.rs, (2 < st.nsteps) ? st.arow + 2048u : kMegaOob);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   mega_load<3>(ring, st.rs, (3 < st.nsteps) ? st.arow + 3072u : kMegaOob);
   static_assert(kMegaPf == 4, "one M0 reaches 4 KiB of LDS");
 }
@@ -246,10 +258,12 @@ __device__ __forceinline__ void mega_visit(const MegaItem& it, const unsigned ch
   const int ks = k0 + U;
 #ifdef MEGA_WAIT0
   if (U < NU) mega_drain(); else mega_wait_slot();      // experiment: a consuming visit waits for EVERY fill in flight
+#elif defined(MEGA_R2_SPACING)
+  if (U < NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf - 2) : "memory"); else mega_wait_slot();   // round 2's form (A/B only)
 #else
-  // a consuming visit also waits for the NEXT slot's fill: the slot it reads was retired one fill earlier (margin for the
-  // landing lag described at mega_load; costs nothing measurable)
-  if (U < NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf - 2) : "memory"); else mega_wait_slot();
+  // R1: a consuming visit waits for its slot's fill AND the next slot's (one fill more than it needs);
+  // R2: a refill-only visit issues its fill with nothing in flight
+  if (U < NU) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kMegaPf - 2) : "memory"); else mega_drain();
 #endif
   if (U < NU) {
     const uint4 af = *reinterpret_cast<const uint4*>(smem + ring + U * 1024 + lane * 16);
@@ -268,12 +282,8 @@ __device__ __forceinline__ void mega_visit(const MegaItem& it, const unsigned ch
   const bool cur = t < it.nsteps;
   const uint32_t off = cur ? it.arow + (uint32_t)(t * 1024) : ((U < it.nsteps_n) ? it.arow_n + (uint32_t)(U * 1024) : kMegaOob);
   mega_load<U>(ring, cur ? it.rsw : it.rs_n, off);
-  // a refill-only visit has nothing between its fill and the next one: keep them 32 cycles apart (the only mitigation the
-  // experiments above support; two such visits per item, next to an epilogue of ~1.5 k cycles)
-#if defined(MEGA_SERIAL)
-  if (U >= NU) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#elif !defined(MEGA_NO_SPACING)
-  if (U >= NU) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#if defined(MEGA_R2_SPACING)
+  if (U >= NU) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // round 2: refill-only fills 32 cycles apart (A/B only)
 #endif
 }
 

@@ -213,9 +213,11 @@ def test_fp8_yolov8m_detections_vs_fp32_oracle(m8):
     be = np.concatenate(be_all)
     print(f"common-anchor fraction {com / tot:.3f}; box error on shared anchors: median {np.median(be):.2f} px, 95 % {np.quantile(be, 0.95):.2f} px, max {be.max():.2f} px")
     for k, (corr, rel) in st.items():
-        assert corr >= (0.96 if k[1] == "box" else 0.85) and rel <= (0.35 if k[1] == "box" else 0.60), (k, corr, rel)
-    assert com / tot >= 0.40
-    assert np.median(be) < 8.0 and np.quantile(be, 0.95) < 30.0
+        # measured (round 3, = the CPU fake-quant study at 640 x 640 to three digits): box 0.989-0.995 / 0.10-0.15,
+        # cls 0.908-0.954 / 0.31-0.44; shared kept anchors 63 %, box error median 1.3 px, 95 % 3.1 px, max 9 px
+        assert corr >= (0.98 if k[1] == "box" else 0.88) and rel <= (0.19 if k[1] == "box" else 0.50), (k, corr, rel)
+    assert com / tot >= 0.55
+    assert np.median(be) < 2.5 and np.quantile(be, 0.95) < 6.0 and be.max() < 25.0
 
 
 def test_fp8_fullsize_1280_batch16_properties(m8):
