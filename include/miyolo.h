@@ -202,8 +202,9 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * 2-D-tile kernel), "dmh_auto" (0 default: conv_impl 3 hands launches with 1-2 tiles per CU to
  * kernel 6), "ncu" (width of the persistent grids, default = the device's CU count), "graph"
  * (1: detect/classify calls are captured into a hipGraph and replayed while shape, thresholds,
- * stream and pointers stay the same - from the SECOND call with that key on: the first runs directly; the head chains stay on
- * the caller's stream while this option is on; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
+ * stream and pointers stay the same - captured on the first call with that key; a capture is kept only if it holds exactly
+ * one kernel node per launch and nothing else (miyolo_graph_info), otherwise the call runs directly; the head chains stay on
+ * the caller's stream; not with "batch_split" / "cls_streams" > 1; needs a non-default stream; default 0), "h2" (1 default: 3x3 stride-1 layers run on the halo-slab kernel conv_h2.h where its tiles cover at least
  * "h2_min_util" percent (70) of the map; "h2_warm" = 1 selects its persistent form), "cls_mega" (1 default: an f16 classifier whose activations fit LDS runs as ONE launch, cls_mega.h; 0: one launch per
  * layer; bit-identical results), "head_lanes" (1 default: detect runs the Detect head's independent conv chains - per level
  * the first conv and the box / class branches behind it - on internal side streams, forked and joined by events around
@@ -229,6 +230,16 @@ int miyolo_write_buffer(miyolo_handle h, int buf, int B, int H, int W, const flo
                         void* workspace, void* stream);
 int miyolo_run_ops(miyolo_handle h, int first, int last, const uint8_t* in, int B, int H, int W,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* hipGraph census (option "graph"): out6 = { graphs held, nodes / kernel nodes of the most recent capture, kernel launches the
+ * captured call issued, captures rejected because those numbers disagreed (the call then ran directly), kernel launches
+ * issued by the handle in total }.  A captured call is replayed only if its graph holds exactly one kernel node per launch
+ * and no other node. */
+int miyolo_graph_info(miyolo_handle h, int32_t* out6);
+
+/* Debug: the NMS candidate counters (anchors above conf per image) of the last detect call's chunk, copied to the host
+ * (synchronises the device).  Lets a test see that a replayed graph resets them (tests/test_gpu_detect.py). */
+int miyolo_debug_candidate_counts(miyolo_handle h, const void* workspace, int B, int32_t* out_host);
 
 /* Bench support: with option "profile" = 1 every op launch is bracketed by hipEvents on the
  * call's stream; miyolo_profile_read synchronises on them and returns, per recorded launch,

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     if (best > a.conf) {
       const int ag = a.aoff[lvl] + a0 + an;
       const int slot = atomicAdd(a.count + b, 1);
-      a.keys[(long)b * a.P + slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ag);
+      // slot < P always holds when the counter was zeroed for this pass (an anchor appends at most once); the test keeps a
+      // counter that was NOT reset (see zero_i32_kernel) from writing past the image's key slots
+      if (slot < a.P) a.keys[(long)b * a.P + slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ag);
       a.cls_idx[(long)b * a.A + ag] = j;
     }
   }
@@ -405,6 +407,20 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const ClsHeadArgs a) {
       if (a.probs) a.probs[(long)b * a.nc + k] = expf(lg[k] - mx) / s;
     }
   }
+}
+
+// The NMS candidate counters are zeroed by a KERNEL, not by hipMemsetAsync: under hipGraph capture (option "graph") every
+// node of a captured call is then a kernel node.  Round 2's first-call capture "replayed into a memory access fault", and
+// it deferred captures to a key's second call without knowing why that helped.  Round 3: the one non-kernel node of that
+// capture was the 4 x B byte hipMemsetAsync of these counters, and launching a graph that holds this memset node is what
+// faults on this runtime (ROCm 7.2): with the reset as a kernel, first-call capture and replays of an older graph after a
+// newer capture are clean (tests/test_gpu_detect.py::test_detect_hip_graph_replay, census 63 kernel nodes = 63 launches);
+// with the memset put back a graph launch faulted again within four calls although candidate slots were range-checked by
+// then (profiles/r03_graph_memset_node_fault.log), so it is the node itself, not a counter overflow.  The memset form is
+// gone from the library (why round 2's second-sighting order survived with it was not looked into further).
+__global__ void zero_i32_kernel(int32_t* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------

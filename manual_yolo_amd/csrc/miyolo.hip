@@ -88,7 +88,8 @@ struct miyolo_engine {
   int cls_streams = 1;      // classify: sub-batches on this many internal streams, joined by events.  Measured at batch 256: 1 stream
                             // 1.12 M img/s, 2: 0.85 M, 4: 0.40 M, 8: 0.29 M (captured in a hipGraph: 0.88 / 0.84 / 0.57 / 0.42 M) - the
                             // front end takes ~8 us per dispatch whether or not the chains are independent; only fewer launches help
-  std::vector<std::vector<unsigned char>> graph_seen;   // keys run once directly (captured on their second call)
+  long launches = 0;        // kernel launches issued by this handle (run_ops, run_nms, counter reset): the census of a capture
+  int graph_nodes = 0, graph_kernel_nodes = 0, graph_launches = 0, graph_rejected = 0;   // of the most recent capture
   std::vector<hipStream_t> lanes;
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
@@ -714,8 +715,9 @@ bool try_bneck(miyolo_engine* h, int i, int last, const Plan& p, const void* in,
 
 int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in, void* ws,
             float* cls_logits, float* cls_probs, hipStream_t s) {
-  // not under graph capture: the event fork / join across streams did not survive a capture here (the replayed graph ran
-  // almost nothing: 140 k "frames/s"), so a captured call keeps everything on the caller's stream
+  // under graph capture a call keeps everything on the caller's stream: round 2 saw the event fork / join across streams
+  // replay an almost empty graph (with_graph's census would now reject such a capture; not pursued - graphs do not speed
+  // the detect step up, its launches already run back to back)
   const bool lanes = h->head_lanes && !h->graph && !h->profile && h->n_lanes > 1 && first == 0 && last == (int)h->ops.size();
   if (lanes) {
     while ((int)h->lanes.size() < h->n_lanes - 1) {
@@ -762,6 +764,7 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
                        ? run_op<half_t>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si)
                        : run_op<float>(h, h->ops[i], p, in, ws, cls_logits, cls_probs, si);
     if (rc) return rc;
+    ++h->launches;                                         // every op (fused or not) is exactly one kernel launch
     if (h->ops[i].kind == MIYOLO_OP_STEM || h->ops[i].kind == MIYOLO_OP_CONV) {
       // the stem+conv and Bottleneck fusions (one absorbed op) keep the FIRST op's output in LDS: that buffer is never written
       const bool kept_in_lds = fusedn == 1;
@@ -793,10 +796,13 @@ int run_nms(miyolo_engine* h, const Plan& p, const float* y, int Bc, int A, floa
   for (int i = 0; i < 8; ++i) a.cls_mask[i] = h->cls_mask[i];
   a.use_mask = h->use_cls_mask;
   if (!prefiltered) {       // else: the decode op filled keys / count / cls_idx (decode_kernel's fused filter)
-    HIP_TRY(h, hipMemsetAsync(a.count, 0, (size_t)Bc * 4, s));
+    hipLaunchKernelGGL(zero_i32_kernel, dim3((Bc + 255) / 256), dim3(256), 0, s, a.count, Bc);      // a kernel, never a memset node
+    ++h->launches;
+    ++h->launches;
     hipLaunchKernelGGL(nms_prefilter_kernel, dim3((A + 255) / 256, Bc), dim3(256), 0, s, a);
   }
   hipLaunchKernelGGL(nms_sort_greedy_kernel, dim3(Bc), dim3(kNmsThreads), (size_t)nms_lds_bytes(max_det), s, a);
+  ++h->launches;
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -823,26 +829,41 @@ int prepare(miyolo_engine* h, int B, int H, int W, size_t ws_bytes, void* ws) {
 // runs directly.
 template <class F>
 int with_graph(miyolo_engine* h, hipStream_t s, const void* key, size_t klen, F&& body) {
-  if (!h->graph || h->profile || s == nullptr || klen > sizeof(miyolo_engine::GraphRec::key)) return body();
+  // batch_split / cls_streams fork over internal streams inside body(): not captured, the call runs directly
+  if (!h->graph || h->profile || s == nullptr || klen > sizeof(miyolo_engine::GraphRec::key) || h->batch_split > 1 || h->cls_streams > 1) return body();
   for (auto& r : h->graphs)
     if (r.klen == klen && !memcmp(r.key, key, klen)) { HIP_TRY(h, hipGraphLaunch(r.ex, s)); return 0; }
-  // a key is captured the SECOND time it is seen: its first call runs directly, so that nothing is launched for the first
-  // time inside a capture (a capture taken on the very first call of an engine replayed into a memory access fault)
-  {
-    bool seen = false;
-    for (auto& k : h->graph_seen) if (k.size() == klen && !memcmp(k.data(), key, klen)) seen = true;
-    if (!seen) {
-      if (h->graph_seen.size() >= 16) h->graph_seen.erase(h->graph_seen.begin());
-      h->graph_seen.emplace_back(static_cast<const unsigned char*>(key), static_cast<const unsigned char*>(key) + klen);
-      return body();
-    }
-  }
+  // A key is captured on its first call (round 2 deferred the capture to the second sighting after a first-call capture
+  // had replayed into a memory access fault; the cause was the captured hipMemsetAsync node, see zero_i32_kernel).  Nothing inside body()
+  // creates streams, events or memory: those are made in miyolo_create / before with_graph.  CENSUS: the captured graph is
+  // used only if it holds exactly one kernel node per launch body() issued and nothing else - a capture that lost launches
+  // (round 2 saw one with the head lanes' cross-stream fork: "140 k frames/s") is thrown away and the call runs directly.
+  const long l0 = h->launches;
   HIP_TRY(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   const int rc = body();
   hipGraph_t g = nullptr;
   const hipError_t e = hipStreamEndCapture(s, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess || !g) return fail(h, MIYOLO_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  {
+    size_t nn = 0;
+    HIP_TRY(h, hipGraphGetNodes(g, nullptr, &nn));
+    std::vector<hipGraphNode_t> nodes(nn);
+    if (nn) HIP_TRY(h, hipGraphGetNodes(g, nodes.data(), &nn));
+    int nk = 0;
+    for (size_t i = 0; i < nn; ++i) {
+      hipGraphNodeType t;
+      HIP_TRY(h, hipGraphNodeGetType(nodes[i], &t));
+      if (t == hipGraphNodeTypeKernel) ++nk;
+    }
+    h->graph_nodes = (int)nn; h->graph_kernel_nodes = nk; h->graph_launches = (int)(h->launches - l0);
+    const bool ok = nk == h->graph_launches && (int)nn == nk;
+    if (!ok) {
+      ++h->graph_rejected;
+      (void)hipGraphDestroy(g);
+      return body();                                       // not captured: run the call directly, keep no graph for this key
+    }
+  }
   hipGraphExec_t ex = nullptr;
   const hipError_t e2 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   if (e2 != hipSuccess) { (void)hipGraphDestroy(g); return fail(h, MIYOLO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
@@ -860,7 +881,6 @@ int with_graph(miyolo_engine* h, hipStream_t s, const void* key, size_t klen, F&
 void drop_graphs(miyolo_engine* h) {
   for (auto& r : h->graphs) { (void)hipGraphExecDestroy(r.ex); (void)hipGraphDestroy(r.g); }
   h->graphs.clear();
-  h->graph_seen.clear();
 }
 
 // Layer table + LDS packing of the one-launch classifier (cls_mega.h) for H x W crops; false: not applicable.
@@ -1050,6 +1070,17 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   }
   build_lanes(h);
   hipError_t e = hipSuccess;
+  {   // the head lanes' streams and events exist from here on: nothing is created on a call (run_ops only looks them up)
+    DevGuard g2(device);
+    for (int i = 1; i < h->n_lanes && e == hipSuccess; ++i) {
+      hipStream_t st;
+      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) == hipSuccess) h->lanes.push_back(st);
+    }
+    for (size_t i = 0; i < h->ops.size() && e == hipSuccess && h->n_lanes > 1; ++i) {
+      hipEvent_t ev;
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) == hipSuccess) h->op_ev.push_back(ev);
+    }
+  }
   if (e == hipSuccess) e = set_conv_attrs_ks<float, 1>();
   if (e == hipSuccess) e = set_conv_attrs_ks<float, 3>();
   if (e == hipSuccess) e = set_conv_attrs_ks<half_t, 1>();
@@ -1270,7 +1301,9 @@ int miyolo_detect(miyolo_handle h, const uint8_t* in, int B, int H, int W, float
       // counters are zeroed first.  Not with the asynchronous NMS, whose previous instance may still read them.
       const bool fused = !async_nms && h->fuse_pre_opt;
       if (fused) {
-        HIP_TRY(h, hipMemsetAsync(static_cast<unsigned char*>(workspace) + p.count_off, 0, (size_t)pc.B * 4, s));
+        int32_t* cnt = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(workspace) + p.count_off);
+        hipLaunchKernelGGL(zero_i32_kernel, dim3((pc.B + 255) / 256), dim3(256), 0, s, cnt, pc.B);
+        ++h->launches;
         h->fuse_pre = 1; h->fuse_conf = conf;
       }
       const int rc_ops = run_ops(h, 0, (int)h->ops.size(), pc, in + (size_t)b0 * H * W * 3, workspace, nullptr, nullptr, s);
@@ -1467,6 +1500,22 @@ int miyolo_write_buffer(miyolo_handle h, int buf, int B, int H, int W, const flo
     hipLaunchKernelGGL(copy_from_f32_kernel<half_t>, dim3(g), dim3(256), 0, s, in, static_cast<half_t*>(dst), n);
     HIP_TRY(h, hipGetLastError());
   }
+  return 0;
+}
+
+int miyolo_graph_info(miyolo_handle h, int32_t* out6) {
+  if (!h || !out6) return MIYOLO_ERR_ARG;
+  out6[0] = (int32_t)h->graphs.size(); out6[1] = h->graph_nodes; out6[2] = h->graph_kernel_nodes; out6[3] = h->graph_launches;
+  out6[4] = h->graph_rejected; out6[5] = (int32_t)h->launches;
+  return 0;
+}
+
+int miyolo_debug_candidate_counts(miyolo_handle h, const void* workspace, int B, int32_t* out_host) {
+  if (!h || !workspace || !out_host || B < 1 || B > h->plan.B) return fail(h, MIYOLO_ERR_ARG, "debug_candidate_counts: B outside the last call's chunk");
+  if (h->desc.task != 0) return fail(h, MIYOLO_ERR_ARG, "not a detection model");
+  DevGuard guard(h->device);
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(out_host, static_cast<const unsigned char*>(workspace) + h->plan.count_off, (size_t)B * 4, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -63,8 +63,9 @@ __global__ __launch_bounds__(256) void nms_prefilter_kernel(const NmsArgs a) {
   if (a.use_mask && !((a.cls_mask[j >> 5] >> (j & 31)) & 1u)) return;
   if (best > a.conf) {
     const int slot = atomicAdd(a.count + b, 1);
-    a.keys[(long)b * a.P + slot] =
-        ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
+    if (slot < a.P)           // always true behind a zeroed counter; see zero_i32_kernel (kernels_misc.h)
+      a.keys[(long)b * a.P + slot] =
+          ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)an);
     a.cls_idx[(long)b * a.A + an] = j;
   }
 }

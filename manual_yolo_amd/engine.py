@@ -73,6 +73,8 @@ SYMBOLS = {
     "miyolo_work": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "miyolo_op_work": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "miyolo_profile_read": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "miyolo_graph_info": (_i, [_vp, _vp]),
+    "miyolo_debug_candidate_counts": (_i, [_vp, _vp, _i, _vp]),
     "miyolo_debug_stamps": (_i, [_vp, _vp]),
     "miyolo_letterbox": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "miyolo_crop_resize": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
@@ -161,6 +163,12 @@ class Engine:
             self.f8_extra = extra
         else:
             cpu_w = build_weight_tensors(prog, sd, bn_eps, dtype, bgr_input)
+        # the conv kernels fetch biases with scalar loads, 16 floats per channel tile, for every tile that starts below
+        # cout rounded up to the widest tile - not range-checked by the hardware (round 2's intermittent memory access fault):
+        # every bias array must carry the padding weights._pad128 gives it
+        for op in prog.ops:
+            if op.kind in (0, 1) and cpu_w[op.bias].numel() < (op.cout + 127) // 128 * 128 + 256:
+                raise MiyoloError(f"{op.name}: bias array of {cpu_w[op.bias].numel()} floats lacks the padding the scalar loads need")
         self.weights = [w.to(self.device) for w in cpu_w]   # kept alive for the handle's lifetime
         bufs = (_Buf * len(prog.bufs))(*[_Buf(c, d, dt, 0) for (c, d, dt) in prog.bufs])
         ops = (_Op * len(prog.ops))()
@@ -441,6 +449,18 @@ class Engine:
         fl, by = C.c_double(), C.c_double()
         self._check(self.lib.miyolo_op_work(self.h, op, B, H, W, C.byref(fl), C.byref(by)), "miyolo_op_work")
         return fl.value, by.value
+
+    def graph_info(self) -> dict:
+        """Census of the hipGraph captures (option graph): see miyolo_graph_info."""
+        v = (C.c_int32 * 6)()
+        self._check(self.lib.miyolo_graph_info(self.h, v), "miyolo_graph_info")
+        return dict(zip(("graphs", "nodes", "kernel_nodes", "launches", "rejected", "total_launches"), list(v)))
+
+    def candidate_counts(self, B: int) -> List[int]:
+        """Debug: anchors above conf per image as the last detect call's score filter counted them."""
+        v = (C.c_int32 * B)()
+        self._check(self.lib.miyolo_debug_candidate_counts(self.h, self._ws.data_ptr(), B, v), "miyolo_debug_candidate_counts")
+        return list(v)
 
     def profile_read(self):
         """[(op_index, conv_variant, ms)] of every op launch since profiling was switched on."""

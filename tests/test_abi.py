@@ -71,6 +71,10 @@ def test_program_and_weight_layouts():
                 assert w.shape[1] % K_ALIGN[dt] == 0 and w.dtype == (torch.float16 if dt == "f16" else torch.float32)
             if r.kind == "stem":
                 assert tuple(w.shape) == (48, 32)
+        # scalar bias loads run up to a widest channel tile past cout: every bias carries a multiple of 128 + 256 floats
+        for op in prog.ops:
+            if op.kind in (0, 1):
+                assert ws[op.bias].numel() >= (op.cout + 127) // 128 * 128 + 256 and float(ws[op.bias][op.cout:].abs().max()) == 0.0
     # upsample / concat never become ops: only 3 op kinds besides conv appear
     assert {o.kind for o in prog.ops} == {0, 1, 2, 3}
     cls = build_program("classify", 13, "n")

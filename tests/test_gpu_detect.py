@@ -481,22 +481,35 @@ def test_fused_bottleneck_changes_no_bit(scale, H, W):
 
 
 def test_detect_hip_graph_replay():
-    """Option graph: a detect call - the fused launches and the NMS included; the head chains stay on the caller's stream
-    under capture - is captured once and replayed; results equal the direct launches, call after call, and a new input
-    pointer re-captures."""
+    """Option graph: a detect call - the fused launches, the counter reset and the NMS included - is captured on its FIRST
+    call and replayed; results equal the direct launches call after call, a new input pointer captures a second graph, and
+    the older graph is replayed after the newer capture (the order in which round 2's first-call capture faulted).  Census:
+    the graph holds exactly one kernel node per launch and nothing else; the NMS candidate counters are reset on every
+    replay.  Round 3 found the cause of round 2's fault: the reset was a hipMemsetAsync, the one non-kernel node of the
+    capture, and launching a graph with that memset node is what faults (reproduced once with the counter-overflow guard in place,
+    profiles/r03_graph_memset_node_fault.log); the reset is a kernel now and no memset is ever captured."""
     sd, meta = synth_state_dict("detect", NC, "n", 0, nc_quirk=False), synth_meta("detect", NC, "n", False)
     eng = engine_from_weights(sd, meta, "f16", 0, bgr_input=False)
     fa = torch.from_numpy(synth_frames(4, 320, 320, seed=31, kind="noise")).cuda()
     fb = torch.from_numpy(synth_frames(4, 320, 320, seed=32, kind="blocks")).cuda()
-    ref = {k: [t.clone() for t in eng.detect(f, conf=0.25, iou=0.7)] for k, f in (("a", fa), ("b", fb))}
+    ref, cnt = {}, {}
+    for k, f in (("a", fa), ("b", fb)):
+        ref[k] = [t.clone() for t in eng.detect(f, conf=0.25, iou=0.7)]
+        cnt[k] = eng.candidate_counts(4)
+    print("candidates per image:", cnt)
     eng.set_option("graph", 1)
     out = tuple(torch.empty_like(t) for t in ref["a"])
-    for i in range(6):
+    for i in range(8):
         k, f = ("a", fa) if i % 3 else ("b", fb)
         eng.detect(f, conf=0.25, iou=0.7, out=out)
         torch.cuda.synchronize()
         for got, want in zip(out, ref[k]):
             assert torch.equal(got, want), f"call {i}"
+        assert eng.candidate_counts(4) == cnt[k], f"call {i}: candidate counters not reset"
+    info = eng.graph_info()
+    print("graph census:", info)
+    assert info["graphs"] == 2 and info["rejected"] == 0
+    assert info["nodes"] == info["kernel_nodes"] == info["launches"] > 50
 
 
 def test_batch_split_runs_part_batches_beside_each_other_unchanged():

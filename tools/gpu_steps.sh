@@ -9,6 +9,7 @@ step() {
   timeout -k 10 "$secs" "$@" > "$log" 2>&1
   local rc=$?
   echo "[step] rc=$rc $log: $(tail -n 1 "$log" | cut -c1-200)"
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[step] timed out / killed: stopping"; exit $rc; fi
+  # 124 / 137: timed out / killed; >= 128: ended by a signal (134 = abort after a GPU memory access fault): no further GPU step
+  if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "[step] timed out / killed / aborted: stopping"; exit $rc; fi
   return 0
 }
