@@ -86,6 +86,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   //             epilogue - a slab that comes from beyond L2 is admitted at the CU's ~11 B/clk miss rate wherever its
   //             DMAs are placed, and the issuing wave waits - and the static tile lists balance worse than the hardware's
   //             dispatch: 1.4 % slower on the whole step.  Kept selectable and tested, off by default.
+  // (Round 3 tried a STAGGER here: the second workgroup a CU receives in the first round - wave slot 1 of its SIMD, read
+  // from HW_REG_HW_ID - started 25 ... 150 % of a tile's tap-loop time late, on the idea that two workgroups of equal
+  // cost dispatched together stay in step and idle the matrix pipe through both's prologues and epilogues at once.
+  // Measured on the whole step: 8 724 / 8 707 / 8 644 / 8 596 / 8 487 / 8 357 frames/s at 0 / 25 / 50 / 75 / 100 / 150 % -
+  // the delay is simply added, nothing is won back; removed.  gpurun_out/r3_sg_*.log)
   const int nblk = PERSIST ? g.ntiles : (int)gridDim.x;
   const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
   const int xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
@@ -244,6 +249,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       }
       return;
     }
+    // (Round 3 tried software-pipelining the fragment reads here - the second 64-byte half's pixel fragments up front and
+    // each of its weight fragments read into the first half's registers as soon as that one's MFMAs were issued, so that a
+    // wave pays one LDS latency per tap instead of two: 8 526 vs 8 663 frames/s over three alternating runs on one box,
+    // -1.6 %; TC = 6 then needs all 256 VGPRs and spills 6-7.  The partner workgroup's wave already fills those gaps.)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk == 1 && !full) break;                     // tail chunk with <= half a row of channels (wave-uniform)
@@ -573,8 +582,8 @@ inline bool h2_shape(int cin, int cout, int B, int H, int W, int elem, int ce, i
   host_magic((uint32_t)g->tiles_x, &g->mg_tx_mul, &g->mg_tx_shift);
   host_magic((uint32_t)g->tiles_y, &g->mg_ty_mul, &g->mg_ty_shift);
   g->bias_bytes = (uint32_t)((cout + 127) / 128 * 128 * 4);
-  g->scratch_off = (g->TW + 2) * ROW_BYTES;          // halo row 0, columns beyond the halo: never read (>= 256 B in every geometry)
-  g->warm = 1;
+  g->scratch_off = 0;          // unused
+  g->warm = 0;                 // unused
   *lds = (size_t)g->slab_bytes + wring;
   *geo = bgeo;
   (void)elem;

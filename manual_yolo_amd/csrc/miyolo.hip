@@ -19,6 +19,7 @@
 #include "conv_dmap.h"
 #include "conv_t2d.h"
 #include "conv_h2.h"
+#include "conv_h3.h"
 // Earlier kernel generations / experiments (persistent halo, warp-specialised, two-workgroup, first halo prototype):
 // compiled only with `build.sh experiments` (-DMIYOLO_EXPERIMENTS=1); the shipped library carries conv_igemm.h
 // (conv_impl 0) and conv_dma.h (1) as the simple bit-exact cross-checks of the default kernels.
@@ -74,6 +75,8 @@ struct miyolo_engine {
   int h2 = 1;               // conv_impl 3: 3x3 stride-1 layers on the halo-slab kernel (conv_h2.h) where its tiles cover the map well
   int h2_warm = 0;          // ... 1: persistent form (next tile's slab issued inside the epilogue): measured 1.4 % SLOWER on the step, off
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
+  int h3 = 0;               // conv_impl 3, f16: 3x3 stride-1 layers on the three-workgroups-per-CU form of the halo-slab kernel (conv_h3.h)
+  int h3_min_util = 85;     // ... where its 128-pixel tiles cover at least this share of the map
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
@@ -432,7 +435,12 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
           HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
         else HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       } else {
-      if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
+      bool done_h3 = false;
+      if constexpr (sizeof(T) == 2) {
+        if (h->conv_impl == 9 && h3_eligible(a, 0.0)) { HIP_TRY(h, launch_conv_h3(a, s)); done_h3 = true; }
+      }
+      if (done_h3) {}
+      else if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
       // narrow layers: the 2-D-tile kernel where there is a residual (it reads it under its K loop), the halo-slab kernel
       // where there is none (f16, detect models only: the classifier's layered path stays on the kernels whose K order the
       // one-launch classifier reproduces bit for bit; per-layer A/B at 48 channels, 160 x 160: 162 vs 182 us without,
@@ -440,7 +448,12 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       else if ((h->conv_impl == 7 || (h->conv_impl == 3 && h->t2d && h->force_wc == 0 &&
                                      !(sizeof(T) == 2 && !a.res && h->desc.task == 0 && h->h2 && h2_eligible<T>(a, 0.01 * h->h2_min_util)))) && t2d_eligible<T>(a))
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
-      else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
+      else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) {
+        bool h3 = false;
+        if constexpr (sizeof(T) == 2) h3 = h->h3 && h3_eligible(a, 0.01 * h->h3_min_util);
+        if constexpr (sizeof(T) == 2) { if (h3) HIP_TRY(h, launch_conv_h3(a, s)); }
+        if (!h3) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
+      }
 #if MIYOLO_EXPERIMENTS
       else if ((h->conv_impl == 6 || (h->conv_impl == 3 && h->dmh_auto && dmh_preferred(a, h->ncu) && h->force_wc == 0)) && dmh_eligible(a))
         HIP_TRY(h, launch_conv_dmh<T>(a, s, h->ncu, h->force_wc, h->force_tc));
@@ -527,12 +540,22 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
                    t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
   const bool s1 = op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample && ob.dtype != MIYOLO_F32 && op.cout % 8 == 0;
   const bool h2_first = h->desc.dtype == MIYOLO_F16 && op.res.buf < 0 && h->desc.task == 0;   // as run_op: narrow layers without a residual
+  if (s1 && h->conv_impl == 9 && h->desc.dtype == MIYOLO_F16) {
+    H2Geom g3; size_t l3; int geo3;
+    const int tc = h2_pick_tc(op.cout, 2);
+    if (h3_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, tc, &g3, &l3, &geo3)) return 8000 + 300 + 50 + tc;
+  }
   if (s1 && (h->conv_impl == 8 || (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && (!t2d || h2_first)))) {
     H2Geom hg; size_t hl; int hgeo;
     const int es = h->desc.dtype == MIYOLO_F16 ? 2 : h->desc.dtype == MIYOLO_F8 ? 1 : 4, tc = h2_pick_tc(op.cout, es);
     if (h2_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, es, 16 / es, tc, &hg, &hl, &hgeo) &&
-        (h->conv_impl == 8 || h2_util(hg, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h2_min_util))
+        (h->conv_impl == 8 || h2_util(hg, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h2_min_util)) {
+      H2Geom g3; size_t l3; int geo3;
+      if (es == 2 && h->conv_impl == 3 && h->h3 && h3_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, tc, &g3, &l3, &geo3) &&
+          h3_util(g3, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h3_min_util)
+        return 8000 + 300 + 50 + tc;                        // conv_h3_kernel<TC>
       return 8000 + 300 + 40 + tc;                          // conv_h2_kernel<T,TC>
+    }
   }
   if (t2d) return 7000 + 300 + 10 + (op.cout + 15) / 16;   // conv_t2d_kernel<T,TC>
   int impl = h->conv_impl >= 3 ? 3 : (h->conv_impl >= 1 ? 1 : 0);
@@ -1096,6 +1119,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_h2_attrs<float>();
   if (e == hipSuccess) e = set_h2_attrs<half_t>();
   if (e == hipSuccess) e = set_h2_attrs<fp8_t>();
+  if (e == hipSuccess) e = set_h3_attrs();
   if (e == hipSuccess) e = set_bneck_attrs();
   if (e == hipSuccess) e = set_stem2_attrs();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 1>();
@@ -1178,6 +1202,8 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
+  if (!strcmp(key, "h3")) { h->h3 = value; return 0; }
+  if (!strcmp(key, "h3_min_util")) { h->h3_min_util = value; return 0; }
   if (!strcmp(key, "cls_mega")) { h->cls_mega = value; return 0; }
   if (!strcmp(key, "head_lanes")) { h->head_lanes = value; return 0; }
   if (!strcmp(key, "nms_async")) { h->nms_async = value; return 0; }

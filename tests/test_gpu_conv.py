@@ -284,3 +284,48 @@ def test_h2_persistent_variant(cin, cout, H, W, B, res):
     y0 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=8)
     assert rel_err(yp, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
     assert np.array_equal(yp, y0)          # same arithmetic in both forms
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B,res", [
+    (96, 96, 80, 80, 2, True),        # 16x8 tiles (slab pitch 18), 1.5 chunks
+    (192, 192, 40, 40, 2, False),     # 40x3 tiles (pitch 42), 120 of 128 pixels used, two channel tiles
+    (288, 288, 20, 20, 3, True),      # 20x6 tiles (pitch 22), 4.5 chunks, three channel tiles
+    (48, 48, 160, 160, 1, True),      # TC = 3: one pair + an unpaired channel tile
+    (192, 64, 80, 80, 1, False),      # head box branch, TC = 4
+    (384, 192, 40, 40, 1, False),
+    (64, 64, 20, 20, 2, False),       # one chunk exactly
+    (96, 72, 68, 80, 1, True),        # letterboxed 544x640 frame: 68-wide map; channel tail (72 of 96)
+    (96, 96, 18, 20, 2, False),       # partial tile rows
+    (16, 16, 16, 16, 3, True),        # a quarter chunk
+    (32, 200, 12, 20, 2, False),      # cout 200 = 2 x 96 + 8
+    (24, 40, 10, 6, 5, True),         # tiny maps, tiles with idle rows / columns
+    (96, 96, 80, 80, 13, True),       # more tiles than the 768 workgroup slots of the chip
+])
+def test_h3_kernel_shapes_and_bit_identity_with_h2(cin, cout, H, W, B, res):
+    """conv_h3.h (conv_impl 9: conv_h2's halo-slab kernel re-cut for three workgroups per CU - 128-pixel tiles, linearly
+    stored slab): against torch, and BIT-IDENTICAL to conv_h2 (same K order, same epilogue arithmetic) on every shape class:
+    the three tile geometries, partial tiles on every side, channel chunk tails, paired / unpaired channel tiles, residual."""
+    dtype = "f16"
+    rng = np.random.default_rng(cin * 7 + cout + H)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype) if res else None
+    y3 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=9)
+    y2 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=8)
+    assert rel_err(y3, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
+    assert np.array_equal(y3, y2)
+
+
+def test_h3_channel_slices():
+    """input = channels 48..95 of a 96-channel buffer, output into channels 96..143 of a 192-channel buffer."""
+    dtype = "f16"
+    rng = np.random.default_rng(79)
+    B, H, W, ld, off, cin, cout = 2, 40, 40, 96, 48, 48, 48
+    x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 3, 1, True, None, B, H, W, dst_ld=192, dst_off=96, impl=9)
+    ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
+    assert rel_err(y[..., 96:96 + cout], ref) < TOL[dtype]
+    assert np.all(y[..., :96] == 7.0) and np.all(y[..., 96 + cout:] == 7.0)
