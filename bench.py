@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--parity-frames", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=50.0)
     ap.add_argument("--profile-out", default="")
+    ap.add_argument("--quant-cache", default="", help="fp8: .npz of the calibration (written if missing, read if present) - keeps the calibration pass out of a profiled run")
     ap.add_argument("--force-spawn", action="store_true", help="take the self-spawn path (one child per rank) even for --gpus 1")
     return ap.parse_args()
 
@@ -360,19 +361,23 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
     # rocprofv3 --pmc passes of the SAME workload (FETCH_SIZE x2 + WRITE_SIZE), with their provenance
     traffic, tsrc = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        import glob
         key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
-        if tj.get("workload") == [B, H, W, dtype]:
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_traffic*.json"))):
+            tj = json.load(open(tf))
+            if tj.get("workload") != [B, H, W, dtype]:
+                continue
             if key in tj["kernels"]:
                 traffic = round(tj["kernels"][key]["traffic_bytes_per_launch"])
-            elif name.startswith("conv_h2<"):
+            elif name.startswith("conv_h2<") or name.startswith("conv_h3<"):
                 # rocprofv3 names the halo-slab kernel per tile geometry (conv_h2<dtype,tc,geo>): launch-weighted mean over them
-                tc = name[name.index(",tc") + 3:-1]
-                ks = [v for k, v in tj["kernels"].items() if k.startswith(f"conv_h2<{dtype},{tc},")]
+                fam, tc = name[:7], name[name.index(",tc") + 3:-1]
+                ks = [v for k, v in tj["kernels"].items() if k.startswith(f"{fam}<{dtype},{tc},")]
                 if ks:
                     traffic = round(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
             if traffic is not None:
-                tsrc = "profiles/r02_traffic.json (rocprofv3 --pmc passes, committed; not re-measured by this run)"
+                tsrc = f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)"
+                break
     except Exception:
         pass
     total_ms = sum(v[1] for v in per.values())
@@ -442,7 +447,14 @@ def main():
         B = args.batch or 256
     frames_np = synth_frames(B, H, W, seed=1 + rank)
     frames = torch.from_numpy(frames_np).to(dev)
-    eng = engine_from_weights(sd, meta, args.dtype, local, bgr_input=False)
+    quant = None
+    if args.dtype == "f8" and args.quant_cache and os.path.exists(args.quant_cache):
+        from manual_yolo_amd.quant import load_spec
+        quant = load_spec(args.quant_cache)
+    eng = engine_from_weights(sd, meta, args.dtype, local, bgr_input=False, quant=quant)
+    if args.dtype == "f8" and args.quant_cache and quant is None and rank == 0:
+        from manual_yolo_amd.quant import save_spec
+        save_spec(eng.quant, args.quant_cache)
 
     def tune(e):
         if args.chunk:

@@ -47,6 +47,22 @@ class QuantSpec:
     buf_mean: Dict[int, np.ndarray] = field(default_factory=dict)   # activation buffer -> per-channel mean activation (bias correction)
 
 
+def save_spec(spec: "QuantSpec", path: str):
+    """QuantSpec -> .npz (so that a profiled run can skip the calibration pass: bench.py --quant-cache)."""
+    d = {f"bs{k}": v for k, v in spec.buf_scale.items()}
+    d.update({f"bm{k}": v for k, v in spec.buf_mean.items()})
+    d["os_idx"] = np.asarray(sorted(spec.out_scale), np.int64)
+    d["os_val"] = np.asarray([spec.out_scale[k] for k in sorted(spec.out_scale)], np.float64)
+    np.savez(path, **d)
+
+
+def load_spec(path: str) -> "QuantSpec":
+    z = np.load(path)
+    bs = {int(k[2:]): z[k] for k in z.files if k.startswith("bs")}
+    bm = {int(k[2:]): z[k] for k in z.files if k.startswith("bm")}
+    return QuantSpec(bs, {int(i): float(v) for i, v in zip(z["os_idx"], z["os_val"])}, bm)
+
+
 def spec_from_amax(prog: Program, amax: Dict[int, float], headroom: float = HEADROOM) -> QuantSpec:
     """amax: op index -> max |activation| written by that op (ops writing activation-dtype buffers)."""
     buf_scale = {i: np.ones(c, np.float32) for i, (c, d, dt) in enumerate(prog.bufs) if dt == -1}

@@ -18,6 +18,6 @@ G[write]="WRITE_SIZE"
 G[tcp]="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE"
 for g in ${PMC_GROUPS:-sq1 sq2 tcc fetch write tcp}; do
   timeout -k 10 240 rocprofv3 --pmc ${G[$g]} --kernel-trace --output-format csv -d "$OUT/$g" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-parity --no-exact-f32 "$@" > "$OUT/$g.log" 2>&1
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-parity --no-exact-f32 --no-classify "$@" > "$OUT/$g.log" 2>&1
   echo "pass $g rc=$? $(ls $OUT/$g/*/ 2>/dev/null | tr '\n' ' ')"
 done
