@@ -53,6 +53,17 @@ inline void h2_geo(int geo, int* tw, int* th, int* hp) {
   *tw = geo == 1 ? 40 : geo == 2 ? 20 : 16; *th = geo == 1 ? 6 : geo == 2 ? 12 : 16; *hp = geo == 1 ? 48 : 24;
 }
 
+// Swizzle of the slab: the 16-byte slot s of halo column hx holds channel chunk s ^ h2_swz<GEO>(hx).  A fragment read takes
+// 16 consecutive halo columns hx0 + dx .. hx0 + dx + 15 (dx = the tap's column) in the lane groups of ds_read_b128
+// ({0-3, 12-15} of one K chunk with {4-11} of its neighbour): (hx >> 1) & 7, the ring kernels' row swizzle, is conflict-free
+// only for EVEN starts - the dx = 1 taps paid two 2-way conflicts per group (PMC round 2: 21 % of the LDS cycles of the
+// 16 x 16 geometry).  For TW = 16 (hx = 0 .. 17) the table below is conflict-free for dx = 0, 1 AND 2 (found by exhaustive
+// search over the lane-group model, tests/test_conv_emulation.py::test_h2_slab_swizzle_is_conflict_free_for_every_tap).
+template <int GEO> __device__ __forceinline__ int h2_swz(int hx) {
+  if constexpr (GEO == 0) return (int)((0xd92dad912240ull >> (3 * hx)) & 7ull);      // 0 0 1 1 2 2 4 4 5 5 6 6 2 2 6 6 0 0
+  else return (hx >> 1) & 7;
+}
+
 template <typename T, int TC, int GEO, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const H2Geom g) {
   constexpr int TW = H2Geo<GEO>::TW, TH = H2Geo<GEO>::TH, HP = H2Geo<GEO>::HP;
@@ -146,10 +157,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   // ---- halo slab DMA: wave w fills halo rows w, w+4, ...; instruction (hy, gx) = LDS rows hy*HP + 8*gx .. +7, halo
   // pixel hx = 8*gx + (lane>>3); the 16-byte slot s of a row holds channel chunk s ^ f(hx), f(h) = (h>>1)&7 - a swizzle
   // by the COLUMN of the halo pixel, so a tap's row offset (dy*HP + dx) moves the address by a constant per dx
-  const int cg0 = (lane & 7) ^ (lane >> 4);                  // chunk of this lane for even gx; odd gx: ^4
   const int hxl = lane >> 3;
-  const int32_t lc0 = hxl * ldB + a.src[0].ch_off * ES + cg0 * 16;          // lane part of the source offset, even / odd gx
-  const int32_t lc1 = hxl * ldB + a.src[0].ch_off * ES + (cg0 ^ 4) * 16;
+  int32_t lc[GX];                                            // lane part of the source offset per DMA group (its chunk column included)
+  uint32_t cvm[GX];                                          // chunk column of this lane in group gx (for the channel-tail test)
+#pragma unroll
+  for (int gx = 0; gx < GX; ++gx) {
+    const int cg = (lane & 7) ^ h2_swz<GEO>(gx * 8 + hxl);
+    lc[gx] = hxl * ldB + a.src[0].ch_off * ES + cg * 16;
+    cvm[gx] = (uint32_t)(cg * CE);
+  }
   // per-lane, tile-dependent part (computed once per workgroup): bit gx of xmask = halo column hx = 8*gx + hxl is
   // inside the image and inside the halo
   uint32_t xmask = 0;
@@ -160,10 +176,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       xmask |= (x >= 0 && x < W && hx < TW + 2) ? (1u << gx) : 0u;
     }
   };
+  auto chunk_mask = [&](int c) -> uint32_t {                 // bit gx: this lane's chunk of group gx lies inside cin
+    uint32_t m = 0;
+#pragma unroll
+    for (int gx = 0; gx < GX; ++gx) m |= ((uint32_t)(c * CPR) + cvm[gx] < (uint32_t)a.cin) ? (1u << gx) : 0u;
+    return m;
+  };
   auto issue_slab = [&](const Tile& t, int c) {
-    // chunk validity folded into the column masks (even / odd gx use different chunk columns)
-    const uint32_t m0_ = ((c * CPR + cg0 * CE) < a.cin) ? 0x55555555u : 0u, m1_ = ((c * CPR + (cg0 ^ 4) * CE) < a.cin) ? 0xAAAAAAAAu : 0u;
-    const uint32_t msk = xmask & (m0_ | m1_);
+    const uint32_t msk = xmask & chunk_mask(c);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int hy = wave + 4 * i;
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
         const uint32_t mrow = yok ? msk : 0u;
 #pragma unroll
         for (int gx = 0; gx < GX; ++gx) {
-          const uint32_t off = (uint32_t)(((gx & 1) ? lc1 : lc0) + sb + gx * 8 * ldB);
+          const uint32_t off = (uint32_t)(lc[gx] + sb + gx * 8 * ldB);
           lds_dma16(rs0, st + gx * 1024, ((mrow >> gx) & 1u) ? off : kOob);
         }
       }
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       const int y = t.y0 - 1 + hy;
       const int32_t sb = ((t.bimg * H + y) * W + t.x0 - 1) * ldB;
       const uint32_t mrow = (y >= 0 && y < H) ? msk : 0u;
-      const uint32_t off = (uint32_t)(((gx & 1) ? lc1 : lc0) + sb + gx * 8 * ldB);
+      const uint32_t off = (uint32_t)(lc[gx] + sb + gx * 8 * ldB);
       lds_dma16(rs0, lds_base + (uint32_t)(hy * HP * ROW_BYTES) + gx * 1024, ((mrow >> gx) & 1u) ? off : kOob);
     }
   };
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int hx = px + dx;
-      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ ((hx >> 1) & 7)) << 4));
+      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ h2_swz<GEO>(hx)) << 4));
     }
   }
   const uint32_t aaddr = lds_off(frow, fq);
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       asm volatile("s_barrier" ::: "memory");                         // every wave is done with the slab of `cur`
       xmask = 0;
       set_x(nxt.x0);
-      nmsk = xmask & ((cg0 * CE < a.cin ? 0x55555555u : 0u) | ((cg0 ^ 4) * CE < a.cin ? 0xAAAAAAAAu : 0u));
+      nmsk = xmask & chunk_mask(0);
     }
     // Without a residual operand the slab's DMAs are spread over all blocks; with one, over the blocks behind the last
     // residual loads only (a load issued behind a slab DMA would wait for it: vmcnt retires in order).

@@ -94,3 +94,36 @@ def test_staging_writes_are_conflict_free():
         lanes = range(g * 8, g * 8 + 8)
         banks = [(_addr(l >> 3, l & 7) // 16) % 8 for l in lanes]   # 128 B = 8 slots of 16 B (32 banks)
         assert len(set(banks)) == 8
+
+
+# ----------------------------------------------------------------------- conv_h2's slab swizzle (round 3)
+H2_SWZ_TW16 = 0xd92dad912240        # csrc/conv_h2.h h2_swz<0>: 3 bits per halo column 0 .. 17
+
+
+def _h2_swz(geo, hx):
+    return (H2_SWZ_TW16 >> (3 * hx)) & 7 if geo == 0 else (hx >> 1) & 7
+
+
+def _h2_conflicts(swz, dx):
+    """extra LDS cycles of one fragment read of the 16 x 16 tile geometry (pixels frow = 0 .. 15 of one row, tap column dx;
+    slab pitch 24 rows, even, so an LDS row's parity is its halo column's): per ds_read_b128 lane group, lanes - 16 slots."""
+    extra = 0
+    for grp in READ_GROUPS:
+        slots = []
+        for l in grp:
+            frow, fq = l & 15, l >> 4
+            hx = frow + dx
+            slots.append(((hx & 1) * 8 + (fq ^ swz(hx))) % 16)
+        extra += max(slots.count(v) for v in set(slots)) - 1          # an N-way conflict costs the group N cycles instead of 1
+    return extra
+
+
+def test_h2_slab_swizzle_is_conflict_free_for_every_tap():
+    """the halo-slab kernel's pixel-fragment reads start at halo column dx = 0, 1 or 2.  The ring
+    kernels' swizzle (hx >> 1) & 7 is conflict-free for even starts only - the dx = 1 taps (three of nine) lose two slots in
+    every lane group; the table of h2_swz<0> loses none for any dx."""
+    table_bits = [(H2_SWZ_TW16 >> (3 * i)) & 7 for i in range(18)]
+    assert table_bits == [0, 0, 1, 1, 2, 2, 4, 4, 5, 5, 6, 6, 2, 2, 6, 6, 0, 0]
+    old = [_h2_conflicts(lambda hx: (hx >> 1) & 7, dx) for dx in (0, 1, 2)]
+    new = [_h2_conflicts(lambda hx: _h2_swz(0, hx), dx) for dx in (0, 1, 2)]
+    assert old == [0, 4, 4] and new == [0, 0, 0], (old, new)      # old: 2-way conflicts in all four groups at dx = 1 and 2 (8 instead of 4 cycles)

@@ -18,6 +18,11 @@ def short(name):
     if k in ("conv_h3_kernel", "conv_bneck_kernel"):
         nums = re.findall(r"Li(\d+)E", name)
         return f"{k.replace('_kernel', '')}<f16,{','.join(nums)}>"
+    d = re.search(r"<(_Float16|float|miyolo::fp8_t)((?:, \w+)*)>", name)          # demangled form (rocprofv3 prints either)
+    if d:
+        dt = {"_Float16": "f16", "float": "f32", "miyolo::fp8_t": "f8"}[d.group(1)]
+        nums = [x for x in re.findall(r", (\w+)", d.group(2)) if x.isdigit()]
+        return f"{k.replace('_kernel', '')}<{dt},{','.join(nums)}>"
     t = re.search(r"I(DF16_|f|NS_5fp8_tE)((?:Li\d+E)*)", name)
     if t:
         dt = "f16" if t.group(1) == "DF16_" else "f8" if "fp8" in t.group(1) else "f32"

@@ -21,6 +21,9 @@ cd $R && bash tools/pmc_profile.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1; tail -2 
 fi
 if [ "$PHASE" != "a" ]; then
 cd $R
+# (each gpurun call lands on a fresh box: write the fp8 calibration cache again, unprofiled, before the counter passes)
+rm -f $QC
+timeout -k 10 300 python3 bench.py --dtype f8 --imgsz 1280 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-exact-f32 --no-classify --no-roofline --quant-cache $QC > gpurun_out/${TAG}_f8_calib.log 2>&1 && echo calib-f8-ok
 bash tools/pmc_profile.sh ${TAG}_f8 --dtype f8 --imgsz 1280 --batch 16 --quant-cache $QC > gpurun_out/pmc_${TAG}_f8.log 2>&1; tail -1 gpurun_out/pmc_${TAG}_f8.log
 timeout -k 10 500 python bench.py --profile-out gpurun_out/perop_${TAG}_f16.json > gpurun_out/${TAG}_f16.log 2>&1; tail -1 gpurun_out/${TAG}_f16.log | cut -c1-160
 timeout -k 10 300 python bench.py --dtype f32 --no-cpu-baseline --profile-out gpurun_out/perop_${TAG}_f32.json > gpurun_out/${TAG}_f32.log 2>&1; tail -1 gpurun_out/${TAG}_f32.log | cut -c1-160
