@@ -16,7 +16,10 @@
 //   * the same 2-slot weight ring, tap loop, K order (chunk, tap, channel), swizzle by halo column and 8-channel epilogue
 //     stores as conv_h2: results are BIT-IDENTICAL to conv_h2's (tests/test_gpu_conv.py).
 // Cost: the weight slab of a tap now feeds half as many MFMAs (L2->LDS weight bytes per FLOP x2, LDS fragment bytes per
-// FLOP x1.6); measured per layer in profiles/r03_per_layer_f16.md.
+// FLOP x1.6).  MEASURED (profiles/r03_h3_vs_h2.md): on the 80 x 80 and 40 x 40 maps every layer is 1-9 % SLOWER than on
+// conv_h2 - the occupancy hypothesis above does not hold there.  Where it wins is the 20 x 20 level, whose layers give
+// conv_h2 384 tiles for 512 workgroup slots and this kernel 768 for 768 (-7 % per layer, profiles/r03_h3_on_p5.md): the
+// engine takes it exactly where its tile count fills the chip better (h3_preferred below), conv_h2 everywhere else.
 #pragma once
 #include <type_traits>
 
@@ -105,7 +108,6 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
   // = halo pixel (hy, hx) = (r / HP, r % HP); its 16-byte slot s = lane & 7 holds channel chunk s ^ f(hx), f(h) = (h >> 1) & 7
   // (the swizzle is by the halo COLUMN, so a tap's offset dy * HP + dx moves a fragment read by a constant per dx)
   int32_t soff[NGW];         // source byte offset of this lane's pixel relative to the tile's halo origin, chunk column included; < 0: never valid
-  uint32_t scg = 0;          // bit i: this lane's chunk column of group i is in the second half of the row (cg >= 4)... kept per group below
   int32_t scol[NGW];         // chunk column cg of this lane in group i (for the channel-tail test)
 #pragma unroll
   for (int i = 0; i < NGW; ++i) {
@@ -117,7 +119,6 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
     soff[i] = ok ? (int32_t)((((int)bimg * H + y) * W + x) * ldB + a.src[0].ch_off * ES + cg * 16) : -1;
     scol[i] = cg;
   }
-  (void)scg;
   auto issue_slab = [&](int c) {
 #pragma unroll
     for (int i = 0; i < NGW; ++i) {
@@ -319,6 +320,17 @@ inline bool h3_geometry(const ConvArgs& a, H2Geom* g, size_t* lds, int* tc, int*
 inline bool h3_eligible(const ConvArgs& a, double min_util) {
   H2Geom g; size_t lds; int tc, geo;
   return h3_geometry(a, &g, &lds, &tc, &geo) && h3_util(g, a.Hout, a.Wout) >= min_util;
+}
+
+// When to prefer conv_h3 (measured, profiles/r03_h3_vs_h2.md and r03_h3_on_p5.md): it is 1-9 % slower per tile-round than
+// conv_h2, so it only pays where conv_h2's tile count fills its 2 x CUs workgroup slots badly and conv_h3's fills its
+// 3 x CUs slots well - the 20 x 20 maps of the P5 level (288 -> 288: 384 tiles on 512 slots against 768 on 768: -7 %).
+// Criterion: round efficiency = tiles / (slots x ceil(tiles / slots)) at least 0.15 better.
+inline bool h3_preferred(const ConvArgs& a, int ncu) {
+  H2Geom g2, g3; size_t l2, l3; int tc, geo2, geo3;
+  if (!h2_geometry<half_t>(a, &g2, &l2, &tc, &geo2) || !h3_geometry(a, &g3, &l3, &tc, &geo3)) return false;
+  auto eff = [](int tiles, int slots) { return (double)tiles / ((double)slots * ((tiles + slots - 1) / slots)); };
+  return eff(g3.ntiles, 3 * ncu) >= eff(g2.ntiles, 2 * ncu) + 0.15;
 }
 
 template <int TC>

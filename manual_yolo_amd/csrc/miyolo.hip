@@ -75,8 +75,10 @@ struct miyolo_engine {
   int h2 = 1;               // conv_impl 3: 3x3 stride-1 layers on the halo-slab kernel (conv_h2.h) where its tiles cover the map well
   int h2_warm = 0;          // ... 1: persistent form (next tile's slab issued inside the epilogue): measured 1.4 % SLOWER on the step, off
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
-  int h3 = 0;               // conv_impl 3, f16: 3x3 stride-1 layers on the three-workgroups-per-CU form of the halo-slab kernel (conv_h3.h)
-  int h3_min_util = 85;     // ... where its 128-pixel tiles cover at least this share of the map
+  int h3 = 2;               // conv_impl 3, f16: 3x3 stride-1 layers on the three-workgroups-per-CU form of the halo-slab kernel (conv_h3.h):
+                            // 0 never, 1 wherever eligible, 2 (default) where its tile count fills the chip better (h3_preferred)
+  int h3_min_util = 75;     // ... and its 128-pixel tiles cover at least this share of the map
+  int h3_max_w = 0;         // ... and the map is at most this wide (0: any width)
   int t2d = 1;              // conv_impl 3: narrow 3x3 layers on 16x16 tiles with resident weights (conv_t2d.h)
   int ablate = 0;           // timing experiments (conv_dma.h), never set in production
   unsigned long long* dbg = nullptr;   // MIYOLO_ABLATE: 256*8*8 u64 stamp buffer (last conv launch wins)
@@ -450,7 +452,8 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
         HIP_TRY(h, launch_conv_t2d<T>(a, s, h->ncu));
       else if (h->conv_impl == 3 && h->h2 && h->force_wc == 0 && h2_eligible<T>(a, 0.01 * h->h2_min_util)) {
         bool h3 = false;
-        if constexpr (sizeof(T) == 2) h3 = h->h3 && h3_eligible(a, 0.01 * h->h3_min_util);
+        if constexpr (sizeof(T) == 2)
+          h3 = h->h3 && (h->h3_max_w == 0 || a.Wout <= h->h3_max_w) && h3_eligible(a, 0.01 * h->h3_min_util) && (h->h3 == 1 || h3_preferred(a, h->ncu));
         if constexpr (sizeof(T) == 2) { if (h3) HIP_TRY(h, launch_conv_h3(a, s)); }
         if (!h3) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
       }
@@ -551,8 +554,10 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
     if (h2_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, es, 16 / es, tc, &hg, &hl, &hgeo) &&
         (h->conv_impl == 8 || h2_util(hg, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h2_min_util)) {
       H2Geom g3; size_t l3; int geo3;
-      if (es == 2 && h->conv_impl == 3 && h->h3 && h3_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, tc, &g3, &l3, &geo3) &&
-          h3_util(g3, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h3_min_util)
+      auto eff = [](int tiles, int slots) { return (double)tiles / ((double)slots * ((tiles + slots - 1) / slots)); };
+      if (es == 2 && h->conv_impl == 3 && h->h3 && (h->h3_max_w == 0 || p.W / ob.down <= h->h3_max_w) && h3_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, tc, &g3, &l3, &geo3) &&
+          h3_util(g3, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h3_min_util &&
+          (h->h3 == 1 || eff(g3.ntiles, 3 * h->ncu) >= eff(hg.ntiles, 2 * h->ncu) + 0.15))
         return 8000 + 300 + 50 + tc;                        // conv_h3_kernel<TC>
       return 8000 + 300 + 40 + tc;                          // conv_h2_kernel<T,TC>
     }
@@ -1204,6 +1209,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
   if (!strcmp(key, "h3")) { h->h3 = value; return 0; }
   if (!strcmp(key, "h3_min_util")) { h->h3_min_util = value; return 0; }
+  if (!strcmp(key, "h3_max_w")) { h->h3_max_w = value; return 0; }
   if (!strcmp(key, "cls_mega")) { h->cls_mega = value; return 0; }
   if (!strcmp(key, "head_lanes")) { h->head_lanes = value; return 0; }
   if (!strcmp(key, "nms_async")) { h->nms_async = value; return 0; }
