@@ -54,9 +54,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     for (int r = 0; r < 4; ++r) bv[tc][r] = a.bias[tc * 16 + q * 4 + r];
 
   const int W3 = a.W * 3;
-  const int startq = (q < 3) ? q * W3 : 8, stepq = (q < 3) ? 1 : W3;
-  const uint32_t m_always = (q < 3) ? 0u : 0xF8u, m_top = (q < 3) ? (q == 0 ? 0xFFu : 0u) : 1u, m_left = (q < 3) ? 7u : 0u;
-
+  // Gather of the 3x3x3 window (round 3).  Lane (pixel frow, q < 3) needs the 9 consecutive bytes of window row q - 8 for
+  // its own K' slot, the 9th for the q = 3 lane of its pixel.  Rounds 1-2 fetched them as 8 single-byte loads per lane
+  // (8 texture-path instructions of 64 scattered bytes per 16 outputs: the kernel sat at 0.32 of its HBM roofline with 67 %
+  // of its wave cycles parked on memory).  Now ONE 12-byte load per lane from the dword below the window start, the window
+  // cut out with v_alignbyte; the q = 3 lanes receive their three bytes from the q = 0..2 lanes by ds_bpermute.  The left
+  // image column (wo = 0: the window starts 3 bytes before the row) loads from the row start and shifts, so no offset is
+  // negative except a row above the image, which is out of range as a whole (zeros).  The frame batch is a multiple of 4
+  // bytes (even H and W), and the last window ends on its last byte: no load reaches past the buffer.
   for (long tile = wave_global; tile < ntiles; tile += nwaves) {
     const long m = tile * 16 + frow;
     const bool vm = m < total;
@@ -66,16 +71,28 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     const int ho = (int)magic_div(rem, a.mg_w_mul, a.mg_w_shift);
     const int wo = (int)rem - ho * a.Wo;
     const int wi0 = 2 * wo - 1, hi0 = 2 * ho - 1;
+    const bool left = wo == 0;
+    const int o = ((b * a.H + hi0 + (q < 3 ? q : 0)) * a.W + wi0) * 3 + (left ? 3 : 0);
+    const bool rowok = vm && q < 3 && !(ho == 0 && q == 0);
+    const uint32_t sh = (uint32_t)o & 3u;
+    const auto d3 = __builtin_amdgcn_raw_buffer_load_b96(rs, rowok ? ((uint32_t)o & ~3u) : 0x80000000u, 0, 0);
+    uint32_t lo = __builtin_amdgcn_alignbyte((uint32_t)d3[1], (uint32_t)d3[0], sh);      // window bytes 0..3
+    uint32_t hi = __builtin_amdgcn_alignbyte((uint32_t)d3[2], (uint32_t)d3[1], sh);      // 4..7
+    uint32_t b8 = ((uint32_t)d3[2] >> (8u * sh)) & 0xFFu;                                 // 8
+    if (left) {                       // loaded from the row start: the true window is three zero bytes, then bytes 0..5 of it
+      b8 = (hi >> 8) & 0xFFu;
+      hi = (hi << 24) | (lo >> 8);
+      lo = lo << 24;
+    }
+    // the q = 3 lanes: byte 8 of window rows 0, 1, 2 of their pixel = b8 of lanes frow, frow + 16, frow + 32
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(frow * 4, (int)b8);
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((frow + 16) * 4, (int)b8);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((frow + 32) * 4, (int)b8);
+    if (q == 3) { lo = r0 | (r1 << 8) | (r2 << 16); hi = 0u; }
     float x[8];
-    // byte j of lane group q (see pack_stem_weight): q<3: row hi0+q, bytes j of the 9-byte run starting at column wi0;
-    // q==3: rows hi0+j (j<3), byte 8.  Offsets are rb + startq + j*stepq with per-lane constants; only the top row
-    // (ho == 0) and the left column (wo == 0) can fall outside the image (even H, W; stride 2), as per-lane bit masks.
-    const int rb = ((b * a.H + hi0) * a.W + wi0) * 3;
-    const uint32_t inval = (vm ? m_always : 0xFFu) | (ho == 0 ? m_top : 0u) | (wo == 0 ? m_left : 0u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t off = (uint32_t)(rb + startq + j * stepq) | (((inval >> j) & 1u) << 31);
-      const uint32_t u = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+      const uint32_t u = ((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xFFu;
       x[j] = a.exact ? (float)u / 255.0f : (float)u * (1.0f / 255.0f);   // f16: rounded to half right after
     }
     f32x4 acc[TCS];
