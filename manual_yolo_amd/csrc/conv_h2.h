@@ -53,16 +53,17 @@ inline void h2_geo(int geo, int* tw, int* th, int* hp) {
   *tw = geo == 1 ? 40 : geo == 2 ? 20 : 16; *th = geo == 1 ? 6 : geo == 2 ? 12 : 16; *hp = geo == 1 ? 48 : 24;
 }
 
-// Swizzle of the slab: the 16-byte slot s of halo column hx holds channel chunk s ^ h2_swz<GEO>(hx).  A fragment read takes
-// 16 consecutive halo columns hx0 + dx .. hx0 + dx + 15 (dx = the tap's column) in the lane groups of ds_read_b128
-// ({0-3, 12-15} of one K chunk with {4-11} of its neighbour): (hx >> 1) & 7, the ring kernels' row swizzle, is conflict-free
-// only for EVEN starts - the dx = 1 taps paid two 2-way conflicts per group (PMC round 2: 21 % of the LDS cycles of the
-// 16 x 16 geometry).  For TW = 16 (hx = 0 .. 17) the table below is conflict-free for dx = 0, 1 AND 2 (found by exhaustive
-// search over the lane-group model, tests/test_conv_emulation.py::test_h2_slab_swizzle_is_conflict_free_for_every_tap).
-template <int GEO> __device__ __forceinline__ int h2_swz(int hx) {
-  if constexpr (GEO == 0) return (int)((0xd92dad912240ull >> (3 * hx)) & 7ull);      // 0 0 1 1 2 2 4 4 5 5 6 6 2 2 6 6 0 0
-  else return (hx >> 1) & 7;
-}
+// Swizzle of the slab (round 3): the 16-byte slot s of halo pixel (hy, hx) holds channel chunk s ^ h2_swz(hx) ^ 4 * (hy & 1 if
+// ROWFLIP).  A fragment read takes 16 pixels in the lane groups of ds_read_b128 ({0-3, 12-15} of one K chunk with {4-11} of its
+// neighbour, i.e. chunk c and c ^ 1); its pixels are 16 consecutive halo columns starting at the tap's dx = 0, 1 or 2 - or,
+// where the tile width is not a multiple of 16, two runs in consecutive halo rows.  The ring kernels' row swizzle
+// (hx >> 1) & 7 is conflict-free only for even starts: the dx = 1 and 2 taps paid 2-way conflicts on every pixel-fragment read
+// (lane-group model: 21 % of the LDS cycles at 16 x 16, the PMC counter said 21.1 %; 22-27 % on the wrapping geometries).
+// ((hx >> 1) & 3) << 1 keeps bit 0 of the chunk position for the c / c ^ 1 pairing and is conflict-free for every start on
+// the 16- and 40-wide tiles; the 20-wide tile additionally flips bit 2 with the halo row's parity (two runs per fragment).
+// tests/test_conv_emulation.py::test_h2_slab_swizzle_is_conflict_free_for_every_tap checks all fragments x taps x geometries.
+__device__ __forceinline__ int h2_swz(int hx) { return ((hx >> 1) & 3) << 1; }
+template <int GEO> struct H2RowFlip { static constexpr bool value = (GEO == 2); };
 
 template <typename T, int TC, int GEO, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const H2Geom g) {
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   uint32_t cvm[GX];                                          // chunk column of this lane in group gx (for the channel-tail test)
 #pragma unroll
   for (int gx = 0; gx < GX; ++gx) {
-    const int cg = (lane & 7) ^ h2_swz<GEO>(gx * 8 + hxl);
+    const int cg = (lane & 7) ^ h2_swz(gx * 8 + hxl) ^ (H2RowFlip<GEO>::value ? 4 * (wave & 1) : 0);   // halo row hy = wave + 4 i: parity of wave
     lc[gx] = hxl * ldB + a.src[0].ch_off * ES + cg * 16;
     cvm[gx] = (uint32_t)(cg * CE);
   }
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int hx = px + dx;
-      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ h2_swz<GEO>(hx)) << 4));
+      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ h2_swz(hx) ^ (H2RowFlip<GEO>::value ? 4 * (py & 1) : 0)) << 4));
     }
   }
   const uint32_t aaddr = lds_off(frow, fq);
@@ -244,16 +245,18 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
     }
   };
 
-  auto compute = [&](int dyoff, auto dx_tag, int slot, bool full) __attribute__((always_inline)) {
+  auto compute = [&](int dy, auto dx_tag, int slot, bool full) __attribute__((always_inline)) {
     constexpr int dx = decltype(dx_tag)::value;
     const unsigned char* ws = smem + SLAB + slot * WSLOT;
-    const unsigned char* xs = smem + dyoff;              // dy * HP * 128: the tap's row offset into the slab
+    // the tap's row offset into the slab; ROWFLIP: an odd dy moves every pixel to a halo row of the other parity (chunk bit 2)
+    const unsigned char* xs = smem + dy * (HP * ROW_BYTES);
+    const uint32_t rf = H2RowFlip<GEO>::value ? (uint32_t)((dy & 1) << 6) : 0u;
     if constexpr (is_fp8<T>::value) {                  // one K = 128 MFMA per tile pair: chunks q and q + 4 of the row
       uint4 bf[TPW][2];                                // the pixel fragments stay, the weight fragments stream (register budget)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) bf[j][kk] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6)));
+        for (int j = 0; j < TPW; ++j) bf[j][kk] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6) ^ rf));
       uint4 a0 = *reinterpret_cast<const uint4*>(ws + aaddr), a1 = *reinterpret_cast<const uint4*>(ws + (aaddr ^ 64u));
 #pragma unroll
       for (int i = 0; i < TC; ++i) {                   // one channel tile ahead, pinned: the scheduler would otherwise hoist all
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
 #pragma unroll
       for (int i = 0; i < TC; ++i) af[i] = *reinterpret_cast<const uint4*>(ws + (aaddr ^ (uint32_t)(kk << 6)) + i * 16 * ROW_BYTES);
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6)));
+      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6) ^ rf));
 #pragma unroll
       for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -328,7 +331,6 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       const bool more = (c + 1 < g.nchunk);
 #pragma unroll 1
       for (int dy = 0; dy < 3; ++dy) {
-        const int dyoff = dy * HP * ROW_BYTES;
 #define MIYOLO_H2_TAP(DX)                                                                           \
         STAMP(s0);                                                                                  \
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                               \
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
         else if (more) issue_w(c + 1, 0, slot ^ 1);                                                 \
         else if (has_next) { nxt = tile_coords(L + xstride); set_w(nxt.n0); issue_w(0, 0, slot ^ 1); } \
         STAMP(s2);                                                                                  \
-        compute(dyoff, std::integral_constant<int, DX>{}, slot, full);                              \
+        compute(dy, std::integral_constant<int, DX>{}, slot, full);                                 \
         STAMP(s3);                                                                                  \
         H2_ACC                                                                                      \
         slot ^= 1;

@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
   };
 
   // ---- slab DMA: wave w fills the 8-row groups w, w + 4, ...; lane (lane >> 3) of a group holds LDS row r = 8 g + (lane >> 3)
-  // = halo pixel (hy, hx) = (r / HP, r % HP); its 16-byte slot s = lane & 7 holds channel chunk s ^ f(hx), f(h) = (h >> 1) & 7
-  // (the swizzle is by the halo COLUMN, so a tap's offset dy * HP + dx moves a fragment read by a constant per dx)
+  // = halo pixel (hy, hx) = (r / HP, r % HP); its 16-byte slot s = lane & 7 holds channel chunk s ^ h2_swz(hx) (^ 4 on odd halo
+  // rows of the 20-wide geometry): conv_h2.h's conflict-free swizzle, by halo column, so a tap's offset dy * HP + dx moves a
+  // fragment read by a constant per dx
   int32_t soff[NGW];         // source byte offset of this lane's pixel relative to the tile's halo origin, chunk column included; < 0: never valid
   int32_t scol[NGW];         // chunk column cg of this lane in group i (for the channel-tail test)
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
     const int r = 8 * (wave + 4 * i) + (lane >> 3);
     const int hy = r / HP, hx = r - hy * HP;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const int cg = (lane & 7) ^ ((hx >> 1) & 7);
+    const int cg = (lane & 7) ^ h2_swz(hx) ^ (H2RowFlip<GEO>::value ? 4 * (hy & 1) : 0);
     const bool ok = (wave + 4 * i < NG) && hy < TH + 2 && y >= 0 && y < H && x >= 0 && x < W;
     soff[i] = ok ? (int32_t)((((int)bimg * H + y) * W + x) * ldB + a.src[0].ch_off * ES + cg * 16) : -1;
     scol[i] = cg;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int hx = px + dx;
-      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ ((hx >> 1) & 7)) << 4));
+      baddr[j][dx] = (uint32_t)((py * HP + hx) * ROW_BYTES + ((fq ^ h2_swz(hx) ^ (H2RowFlip<GEO>::value ? 4 * (py & 1) : 0)) << 4));
     }
   }
   const uint32_t aaddr = lds_off(frow, fq);
@@ -158,10 +159,11 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
     for (int j = 0; j < TPW; ++j) acc[i][j] = bf;
   }
 
-  auto compute = [&](int dyoff, auto dx_tag, int slot, bool full) __attribute__((always_inline)) {
+  auto compute = [&](int dy, auto dx_tag, int slot, bool full) __attribute__((always_inline)) {
     constexpr int dx = decltype(dx_tag)::value;
     const unsigned char* ws = smem + SLAB + slot * WSLOT;
-    const unsigned char* xs = smem + dyoff;
+    const unsigned char* xs = smem + dy * (HP * ROW_BYTES);
+    const uint32_t rf = H2RowFlip<GEO>::value ? (uint32_t)((dy & 1) << 6) : 0u;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk == 1 && !full) break;                     // tail chunk with <= half a row of channels (wave-uniform)
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
 #pragma unroll
       for (int i = 0; i < TC; ++i) af[i] = *reinterpret_cast<const uint4*>(ws + (aaddr ^ (uint32_t)(kk << 6)) + i * 16 * ROW_BYTES);
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6)));
+      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + (baddr[j][dx] ^ (uint32_t)(kk << 6) ^ rf));
 #pragma unroll
       for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -185,12 +187,11 @@ __global__ __launch_bounds__(256, 3) void conv_h3_kernel(const ConvArgs a, const
     const bool more = (c + 1 < g.nchunk);
 #pragma unroll 1
     for (int dy = 0; dy < 3; ++dy) {
-      const int dyoff = dy * HP * ROW_BYTES;
 #define MIYOLO_H3_TAP(DX)                                                                           \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                               \
       if (dy * 3 + (DX) < 8) issue_w(c, dy * 3 + (DX) + 1, slot ^ 1);                             \
       else if (more) issue_w(c + 1, 0, slot ^ 1);                                                 \
-      compute(dyoff, std::integral_constant<int, DX>{}, slot, full);                              \
+      compute(dy, std::integral_constant<int, DX>{}, slot, full);                                 \
       slot ^= 1;
       MIYOLO_H3_TAP(0) MIYOLO_H3_TAP(1) MIYOLO_H3_TAP(2)
 #undef MIYOLO_H3_TAP

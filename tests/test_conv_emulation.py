@@ -96,34 +96,44 @@ def test_staging_writes_are_conflict_free():
         assert len(set(banks)) == 8
 
 
-# ----------------------------------------------------------------------- conv_h2's slab swizzle (round 3)
-H2_SWZ_TW16 = 0xd92dad912240        # csrc/conv_h2.h h2_swz<0>: 3 bits per halo column 0 .. 17
+# ----------------------------------------------------------------------- conv_h2 / conv_h3 slab swizzle (round 3)
+def _h2_swz(hx):
+    return ((hx >> 1) & 3) << 1          # csrc/conv_h2.h h2_swz
 
 
-def _h2_swz(geo, hx):
-    return (H2_SWZ_TW16 >> (3 * hx)) & 7 if geo == 0 else (hx >> 1) & 7
-
-
-def _h2_conflicts(swz, dx):
-    """extra LDS cycles of one fragment read of the 16 x 16 tile geometry (pixels frow = 0 .. 15 of one row, tap column dx;
-    slab pitch 24 rows, even, so an LDS row's parity is its halo column's): per ds_read_b128 lane group, lanes - 16 slots."""
-    extra = 0
-    for grp in READ_GROUPS:
-        slots = []
-        for l in grp:
-            frow, fq = l & 15, l >> 4
-            hx = frow + dx
-            slots.append(((hx & 1) * 8 + (fq ^ swz(hx))) % 16)
-        extra += max(slots.count(v) for v in set(slots)) - 1          # an N-way conflict costs the group N cycles instead of 1
-    return extra
+def _fragment_conflicts(TW, NPX, swz, rowflip):
+    """(worst multiplicity, mean extra LDS cycles per lane group) over every pixel fragment x tap column dx of a TW-wide tile of
+    NPX pixels: lane (frow, fq) reads pixel p = 16 t + frow -> halo pixel (py, px + dx); slot = LDS row parity (= halo column
+    parity: the slab pitch is even) x chunk position fq ^ swz(hx) ^ 4 (py & 1 if rowflip)."""
+    worst, extra, n = 1, 0, 0
+    for t in range((NPX + 15) // 16):
+        for dx in (0, 1, 2):
+            for grp in READ_GROUPS:
+                slots = {}
+                for l in grp:
+                    frow, fq = l & 15, l >> 4
+                    p = 16 * t + frow
+                    if p >= NPX:
+                        p = 0                      # lanes past the tile read pixel 0
+                    py, px = divmod(p, TW)
+                    hx = px + dx
+                    pos = fq ^ swz(hx) ^ (4 * (py & 1) if rowflip else 0)
+                    slots.setdefault(((hx & 1) * 8 + (pos & 7)) % 16, set()).add((py, hx, fq))
+                m = max(len(v) for v in slots.values())
+                worst = max(worst, m); extra += m - 1; n += 1
+    return worst, extra / n
 
 
 def test_h2_slab_swizzle_is_conflict_free_for_every_tap():
-    """the halo-slab kernel's pixel-fragment reads start at halo column dx = 0, 1 or 2.  The ring
-    kernels' swizzle (hx >> 1) & 7 is conflict-free for even starts only - the dx = 1 taps (three of nine) lose two slots in
-    every lane group; the table of h2_swz<0> loses none for any dx."""
-    table_bits = [(H2_SWZ_TW16 >> (3 * i)) & 7 for i in range(18)]
-    assert table_bits == [0, 0, 1, 1, 2, 2, 4, 4, 5, 5, 6, 6, 2, 2, 6, 6, 0, 0]
-    old = [_h2_conflicts(lambda hx: (hx >> 1) & 7, dx) for dx in (0, 1, 2)]
-    new = [_h2_conflicts(lambda hx: _h2_swz(0, hx), dx) for dx in (0, 1, 2)]
-    assert old == [0, 4, 4] and new == [0, 0, 0], (old, new)      # old: 2-way conflicts in all four groups at dx = 1 and 2 (8 instead of 4 cycles)
+    """the halo-slab kernels' pixel-fragment reads start at halo column dx = 0, 1 or 2 (and wrap a halo
+    row where the tile width is not a multiple of 16).  The ring kernels' swizzle (hx >> 1) & 7 pays 2- and 3-way conflicts
+    there; h2_swz (+ the row-parity flip of the 20-wide geometry) pays none, on every geometry of conv_h2 and conv_h3."""
+    old = lambda hx: (hx >> 1) & 7  # noqa: E731
+    assert _fragment_conflicts(16, 256, old, False)[0] == 2 and _fragment_conflicts(20, 240, old, False)[0] == 3
+    assert abs(_fragment_conflicts(16, 256, old, False)[1] - 2 / 3) < 1e-9        # x 4 reads of 10 per half: 21 % of the LDS cycles
+    for TW, NPX, flip in ((16, 256, False), (40, 240, False), (20, 240, True),      # conv_h2: 16x16, 40x6, 20x12
+                          (16, 128, False)):                                        # conv_h3: 16x8
+        assert _fragment_conflicts(TW, NPX, _h2_swz, flip) == (1, 0.0), (TW, NPX)
+    # conv_h3's 120-pixel tiles (40x3, 20x6): the last fragment is half empty and the idle lanes (which read pixel 0) meet
+    # the live ones in one slot of one fragment in eight
+    assert _fragment_conflicts(40, 120, _h2_swz, False) == (2, 0.125) and _fragment_conflicts(20, 120, _h2_swz, True) == (2, 0.125)

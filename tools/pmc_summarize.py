@@ -16,7 +16,7 @@ def short(name):
         return name[:40]
     k = m.group(1)
     if k in ("conv_h3_kernel", "conv_bneck_kernel"):
-        nums = re.findall(r"Li(\d+)E", name)
+        nums = re.findall(r"Li(\d+)E", name) or re.findall(r"[<,] ?(\d+)(?=[,>])", name)
         return f"{k.replace('_kernel', '')}<f16,{','.join(nums)}>"
     d = re.search(r"<(_Float16|float|miyolo::fp8_t)((?:, \w+)*)>", name)          # demangled form (rocprofv3 prints either)
     if d:
