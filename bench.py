@@ -327,6 +327,33 @@ def kernel_name(cfg, kind, dtype):
     return "%s<%s,k%d,wc%d,tc%d>" % (fam, dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)
 
 
+def lookup_traffic(name, B, H, W, dtype):
+    """HBM traffic per launch of kernel `name` (bench naming, e.g. conv_h2<f16,k3,wc4,tc6>) from the committed rocprofv3 --pmc
+    passes of the SAME workload (profiles/r03_traffic*.json: FETCH_SIZE x 2 + WRITE_SIZE per launch, tools/pmc_traffic.py);
+    (None, None) when no committed pass matches the workload.  It cannot be measured from inside this process."""
+    import glob
+    key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_traffic*.json"))):
+        try:
+            tj = json.load(open(tf))
+        except (OSError, ValueError):
+            continue
+        if tj.get("workload") != [B, H, W, dtype]:
+            continue
+        traffic = None
+        if key in tj["kernels"]:
+            traffic = round(tj["kernels"][key]["traffic_bytes_per_launch"])
+        elif name.startswith("conv_h2<") or name.startswith("conv_h3<"):
+            # rocprofv3 names the halo-slab kernels per tile geometry (conv_h2<dtype,tc,geo>): launch-weighted mean over them
+            fam, tc = name[:7], name[name.index(",tc") + 3:-1]
+            ks = [v for k, v in tj["kernels"].items() if k.startswith(f"{fam}<{dtype},{tc},")]
+            if ks:
+                traffic = round(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
+        if traffic is not None:
+            return traffic, f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)"
+    return None, None
+
+
 def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
     import torch
     eng.set_option("profile", 1)
@@ -359,27 +386,7 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
     name, (n, ms, fl, by) = max(per.items(), key=lambda kv: kv[1][1])
     # HBM traffic per launch of that kernel: not measurable from inside this process - taken from the committed
     # rocprofv3 --pmc passes of the SAME workload (FETCH_SIZE x2 + WRITE_SIZE), with their provenance
-    traffic, tsrc = None, None
-    try:
-        import glob
-        key = name.replace(",k", ",").replace(",wc", ",").replace(",tc", ",")
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_traffic*.json"))):
-            tj = json.load(open(tf))
-            if tj.get("workload") != [B, H, W, dtype]:
-                continue
-            if key in tj["kernels"]:
-                traffic = round(tj["kernels"][key]["traffic_bytes_per_launch"])
-            elif name.startswith("conv_h2<") or name.startswith("conv_h3<"):
-                # rocprofv3 names the halo-slab kernel per tile geometry (conv_h2<dtype,tc,geo>): launch-weighted mean over them
-                fam, tc = name[:7], name[name.index(",tc") + 3:-1]
-                ks = [v for k, v in tj["kernels"].items() if k.startswith(f"{fam}<{dtype},{tc},")]
-                if ks:
-                    traffic = round(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks))
-            if traffic is not None:
-                tsrc = f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)"
-                break
-    except Exception:
-        pass
+    traffic, tsrc = lookup_traffic(name, B, H, W, dtype)
     total_ms = sum(v[1] for v in per.values())
     conv_fl = sum(v[2] for k, v in per.items() if k.startswith("conv")); conv_ms = sum(v[1] for k, v in per.items() if k.startswith("conv"))
     if fl > 0:

@@ -29,3 +29,14 @@ def test_map_drops_with_missing_shifted_and_extra_boxes():
     extra = [np.concatenate([x, _dets(rng, 30) * np.array([1, 1, 1, 1, 0.1, 1], np.float32)]) for x in g]   # low-score false positives
     assert bench.map50_95(extra, g) > 0.99
     assert bench.map50_95([np.zeros((0, 6), np.float32)] * 2, g) == 0.0
+
+
+def test_roofline_traffic_lookup_finds_the_committed_pmc_passes():
+    """bench.py's roofline.traffic comes from profiles/r03_traffic*.json, matched by workload; the headline workload (f16) and
+    config 5 (fp8, 1280 x 1280 x 16) must both resolve for their dominant halo-slab kernels."""
+    import bench
+    t, src = bench.lookup_traffic("conv_h2<f16,k3,wc4,tc6>", 64, 640, 640, "f16")
+    assert t is not None and 80e6 < t < 300e6 and "r03_traffic" in src
+    t8, src8 = bench.lookup_traffic("conv_h2<f8,k3,wc4,tc3>", 16, 1280, 1280, "f8")
+    assert t8 is not None and t8 > 10e6 and "f8" in src8
+    assert bench.lookup_traffic("conv_h2<f16,k3,wc4,tc6>", 32, 640, 640, "f16") == (None, None)      # no pass of that workload

@@ -22,6 +22,5 @@ python tools/per_layer_table.py gpurun_out/perop_${TAG}_f8_1280.json f8 profiles
   done
   echo; echo "## device pre-processing (tools/bench_preprocess.py)"; echo '```'; grep '^{' gpurun_out/${TAG}_pre.log; echo '```'
 } > profiles/${TAG}_bench_lines.md
-[ -f gpurun_out/stamp_mega.log ] && cp gpurun_out/stamp_mega.log profiles/${TAG}_cls_mega_stamps.log
-[ -f gpurun_out/stamps_h2e.log ] && grep -v amdgpu.ids gpurun_out/stamps_h2e.log > profiles/${TAG}_h2_stamps.log
+[ -f gpurun_out/${TAG/r0/r}_stamps_h2.log ] && grep -v amdgpu.ids gpurun_out/${TAG/r0/r}_stamps_h2.log > profiles/${TAG}_h2_stamps.log
 ls -la profiles | grep ${TAG}_
