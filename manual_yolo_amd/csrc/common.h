@@ -10,6 +10,10 @@
 #define MIYOLO_ABLATE 0
 #endif
 #define ABL(bit) (MIYOLO_ABLATE == 1 && (a.ablate & (bit)))
+// cache policy of the conv kernels' output stores (aux of raw_buffer_store: 0 default, 2 nt, 16 sc1, 17 sc0 sc1)
+#ifndef MIYOLO_ST_AUX
+#define MIYOLO_ST_AUX 0
+#endif
 #if MIYOLO_ABLATE
 #define STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
 #else
@@ -207,13 +211,13 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, const __amdgpu_
   const uint32_t so = ok ? (uint32_t)((m * a.dst_ld + a.dst_choff + n) * OS) : 0x80000000u;
   if constexpr (OS == 4) {
     v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, MIYOLO_ST_AUX);
   } else if constexpr (OS == 2) {
     f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, MIYOLO_ST_AUX);
   } else {
     const float q = a.out_inv_scale;
-    __builtin_amdgcn_raw_buffer_store_b32((int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), rdst, so, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32((int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), rdst, so, 0, MIYOLO_ST_AUX);
   }
 }
 

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void conv_bneck_kernel(const BneckArgs a) {
             v[q] = x + (float)h[q];
           }
           const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2), 0, MIYOLO_ST_AUX);
         }
       }
     }

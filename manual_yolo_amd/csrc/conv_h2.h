@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
   const int xlen = xq + (xcd < xr ? 1 : 0);
   const int xstride = PERSIST ? (int)(gridDim.x >> 3) : 1;
   if (slot_ >= xlen) return;
+  // (Round 3 tried walking every XCD's chunk from its END in alternate / all launches, so that a layer starts on the tiles its
+  // producer wrote last, still in that XCD's L2: 8 742 / 8 729 / 8 675 frames/s for off / all / alternate - no effect.  What
+  // serves a layer's input is the 256 MB Infinity Cache, which does not care about order: with the producers' stores marked
+  // sc1 or nt the step loses 6 % / 18 %, profiles/r03_store_policy_ab.log.)
   int L = xstart + slot_;
   int tleft = PERSIST ? (xlen - slot_ - 1) / xstride : 0;      // tiles after the first
 
@@ -447,15 +451,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
       if constexpr (ES == 1) {
         const float q = a.out_inv_scale;
         const v2i_t o = {(int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), (int)pack_fp8x4(v[4] * q, v[5] * q, v[6] * q, v[7] * q)};
-        __builtin_amdgcn_raw_buffer_store_b64(o, rdst, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(o, rdst, so, 0, MIYOLO_ST_AUX);
       } else if constexpr (ES == 4) {
         const v4ie_t o0 = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
         const v4ie_t o1 = {__float_as_int(v[4]), __float_as_int(v[5]), __float_as_int(v[6]), __float_as_int(v[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, rdst, so + 16u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rdst, so, 0, MIYOLO_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, rdst, so + 16u, 0, MIYOLO_ST_AUX);
       } else {
         const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, MIYOLO_ST_AUX);
       }
       pieces_after_block(std::integral_constant<int, ip * TPW + j>{});
     };
@@ -526,13 +530,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvArgs a, const
         const uint32_t so = ok ? (uint32_t)((mpix[j] * a.dst_ld + a.dst_choff + n) * ES) : kOob;
         if constexpr (ES == 1) {
           const float q = a.out_inv_scale;
-          __builtin_amdgcn_raw_buffer_store_b32((int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), rdst, so, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32((int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), rdst, so, 0, MIYOLO_ST_AUX);
         } else if constexpr (ES == 4) {
           const v4ie_t o = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rdst, so, 0, MIYOLO_ST_AUX);
         } else {
           const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, so, 0, MIYOLO_ST_AUX);
         }
         pieces_after_block(std::integral_constant<int, NPAIR * TPW + j>{});
       };
