@@ -34,7 +34,7 @@ constexpr int kS2Oh = 8, kS2Ow = 16;                        // output tile of la
 constexpr int kS2Sh = 2 * kS2Oh + 1, kS2Sw = 2 * kS2Ow + 1;  // the stem pixels it reads: 17 x 33
 
 template <int TCS, int TC1> struct Stem2Geo {
-  static constexpr int C0 = TCS * 16, C1 = TC1 * 16, SROW = C0 * 2, CPT = C0 / 8, NCH = 9 * CPT, NG = (NCH + 3) / 4, WROW = NG * 64 + 16;
+  static constexpr int C0 = TCS * 16, C1 = TC1 * 16, SROW = C0 * 2, CPT = C0 / 8, NCH = 9 * CPT, NG = (NCH + 3) / 4, WROW = NG * 64 + 32;   // pitch = 2 (mod 4) chunks: conflict-free weight fragments (conv_bneck.h)
   static constexpr int NSPX = kS2Sh * kS2Sw, NST = (NSPX + 15) / 16, TPW = (NST + 7) / 8;     // stem pixels, their 16-pixel tiles, tiles per wave
   static constexpr int W_BYTES = C1 * WROW, KOFF_BYTES = NG * 16;
   static constexpr int S_OFF = W_BYTES + KOFF_BYTES, S_BYTES = NSPX * SROW;

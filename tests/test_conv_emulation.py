@@ -137,3 +137,45 @@ def test_h2_slab_swizzle_is_conflict_free_for_every_tap():
     # conv_h3's 120-pixel tiles (40x3, 20x6): the last fragment is half empty and the idle lanes (which read pixel 0) meet
     # the live ones in one slot of one fragment in eight
     assert _fragment_conflicts(40, 120, _h2_swz, False) == (2, 0.125) and _fragment_conflicts(20, 120, _h2_swz, True) == (2, 0.125)
+
+
+def _group_cycles(addr_of_lane):
+    """Mean LDS cycles per ds_read_b128 lane group (1.0 = conflict-free): bank = 16-byte slot mod 16."""
+    tot = 0
+    for grp in READ_GROUPS:
+        slots = {}
+        for l in grp:
+            a = addr_of_lane(l)
+            slots.setdefault((a // 16) % 16, set()).add(a)
+        tot += max(len(v) for v in slots.values())
+    return tot / len(READ_GROUPS)
+
+
+def test_bneck_lds_layout_bank_model():
+    """conv_bneck.h (C = 48): weight-row pitch and halo-row pitch of the X tile.  Round 2's layout (odd weight pitch 57 chunks,
+    dense 20-pixel halo rows) costs 2.0 / 1.74 cycles per lane group on the weight / conv-A pixel fragments - 43 % of all the
+    kernel's read cycles, the counter said 45.6 % (profiles/r03_pmc_f16_b64.md); pitch 58 and 124 chunks cost 1.0 / 1.08."""
+    CPT, NCH, NG = 6, 54, 14
+
+    def weights(wrow):
+        return sum(_group_cycles(lambda l, kg=kg: (l & 15) * wrow + (l >> 4) * 16 + kg * 64) for kg in range(NG)) / NG
+
+    def conv_a_pixels(xpc):
+        def ko(q):
+            tap, co = divmod(q, CPT)
+            return ((tap // 3) * xpc + (tap % 3) * CPT + co) * 16 if q < NCH else 0
+        tot = 0
+        for pt in range(21):
+            for kg in range(NG):
+                def addr(l, pt=pt, kg=kg):
+                    p = pt * 16 + (l & 15)
+                    p = p if p < 324 else 0
+                    return ((p // 18) * xpc + (p % 18) * CPT) * 16 + ko(kg * 4 + (l >> 4))
+                tot += _group_cycles(addr)
+        return tot / (21 * NG)
+
+    assert weights(912) == 2.0 and weights(928) == 1.0
+    assert 1.7 < conv_a_pixels(120) < 1.8 and conv_a_pixels(124) < 1.1
+    # the shares of the old layout: conv A reads 3 weight + 2.625 pixel fragments per k group, conv B 3 + 2 (its pixel reads: 1.04)
+    old = 3 * 2.0 + 2.625 * conv_a_pixels(120) + 3 * 2.0 + 2 * 1.04
+    assert 0.40 < 1 - (3 + 2.625 + 3 + 2) / old < 0.46
