@@ -20,6 +20,7 @@
 #include "conv_t2d.h"
 #include "conv_h2.h"
 #include "conv_h3.h"
+#include "conv_pw.h"
 // Earlier kernel generations / experiments (persistent halo, warp-specialised, two-workgroup, first halo prototype):
 // compiled only with `build.sh experiments` (-DMIYOLO_EXPERIMENTS=1); the shipped library carries conv_igemm.h
 // (conv_impl 0) and conv_dma.h (1) as the simple bit-exact cross-checks of the default kernels.
@@ -75,6 +76,7 @@ struct miyolo_engine {
   int h2 = 1;               // conv_impl 3: 3x3 stride-1 layers on the halo-slab kernel (conv_h2.h) where its tiles cover the map well
   int h2_warm = 0;          // ... 1: persistent form (next tile's slab issued inside the epilogue): measured 1.4 % SLOWER on the step, off
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
+  int pw = 0;               // 1: conv_impl 3, f16: eligible 1x1 layers on the streaming kernel (conv_pw.h) - round-3 experiment, 6-8 % slower than the ring kernel: off
   int h3 = 2;               // conv_impl 3, f16: 3x3 stride-1 layers on the three-workgroups-per-CU form of the halo-slab kernel (conv_h3.h):
                             // 0 never, 1 wherever eligible, 2 (default) where its tile count fills the chip better (h3_preferred)
   int h3_min_util = 75;     // ... and its 128-pixel tiles cover at least this share of the map
@@ -464,6 +466,9 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       else if (h->conv_impl == 4 && halop_eligible(a)) HIP_TRY(h, launch_conv_halop<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl == 2 && halo_eligible(a)) HIP_TRY(h, launch_conv_halo<T>(a, s, h->force_wc, h->force_tc));
 #endif
+      else if (sizeof(T) == 2 && h->conv_impl == 3 && h->pw && h->force_wc == 0 && pw_eligible(a)) {
+        HIP_TRY(h, launch_conv_pw(a, s, h->ncu));
+      }
       else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
       else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
       else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
@@ -532,6 +537,17 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
   return 0;
 }
 
+// pw_eligible (conv_pw.h) from the op description alone (conv_cfg_id has no ConvArgs)
+bool pw_op_eligible(const miyolo_engine* h, const miyolo_op& op) {
+  const miyolo_buf& ob = h->bufs[op.dst.buf];
+  if (op.ksize != 1 || op.stride != 1 || op.res.buf >= 0 || ob.dtype == MIYOLO_F32 || op.cout % 96) return false;
+  if (op.n_src == 2 && (op.src[0].ch_cnt % 64 || op.src[1].ch_cnt % 32)) return false;
+  if (op.n_src == 1 && op.src[0].ch_cnt % 32) return false;
+  for (int i = 0; i < op.n_src; ++i)
+    if (h->bufs[op.src[i].buf].channels % 8 || op.src[i].ch_off % 8) return false;
+  return ob.channels % 8 == 0 && op.dst.ch_off % 8 == 0;
+}
+
 int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   if (op.kind != MIYOLO_OP_CONV) return 0;
   const miyolo_buf& ob = h->bufs[op.dst.buf];
@@ -563,6 +579,8 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
     }
   }
   if (t2d) return 7000 + 300 + 10 + (op.cout + 15) / 16;   // conv_t2d_kernel<T,TC>
+  if (op.ksize == 1 && h->conv_impl == 3 && h->pw && h->force_wc == 0 && h->desc.dtype == MIYOLO_F16 && pw_op_eligible(h, op))
+    return 10000 + 100 + pw_nt(op.cout);                    // conv_pw_kernel<NT,NB>: 10112 / 10106
   int impl = h->conv_impl >= 3 ? 3 : (h->conv_impl >= 1 ? 1 : 0);
   ConvCfg c = impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
 #if MIYOLO_EXPERIMENTS
@@ -1126,6 +1144,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_h2_attrs<fp8_t>();
   if (e == hipSuccess) e = set_h3_attrs();
   if (e == hipSuccess) e = set_bneck_attrs();
+  if (e == hipSuccess) e = set_pw_attrs();
   if (e == hipSuccess) e = set_stem2_attrs();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 3>();
@@ -1207,6 +1226,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   }
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
+  if (!strcmp(key, "pw")) { h->pw = value; return 0; }
   if (!strcmp(key, "h3")) { h->h3 = value; return 0; }
   if (!strcmp(key, "h3_min_util")) { h->h3_min_util = value; return 0; }
   if (!strcmp(key, "h3_max_w")) { h->h3_max_w = value; return 0; }

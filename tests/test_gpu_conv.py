@@ -329,3 +329,65 @@ def test_h3_channel_slices():
     ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
     assert rel_err(y[..., 96:96 + cout], ref) < TOL[dtype]
     assert np.all(y[..., :96] == 7.0) and np.all(y[..., 96 + cout:] == 7.0)
+
+
+# ---- conv_pw.h: the streaming 1x1 kernel (conv_impl 3, option pw = 1; the default, pw = 0, is the ring kernel conv_dmap.h)
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,W,B", [
+    (96, 96, 16, 16, 2),        # K = 1.5 steps (half step + void steps), one channel tile of 96
+    (192, 96, 20, 12, 3),       # model.2.cv2's shape class; pixel count not a multiple of anything
+    (192, 192, 16, 16, 2),      # BN = 192
+    (576, 192, 24, 24, 2),      # 9 K steps + 3 void ones
+    (384, 384, 8, 8, 5),        # two channel tiles sharing a pixel range
+    (1152, 576, 6, 6, 3),       # three channel tiles, 18 steps
+    (576, 288, 6, 6, 3),        # 288 = 3 x 96 (SPPF cv1)
+    (64, 192, 10, 10, 1),       # one K step only; fewer pixels than one tile per workgroup
+    (128, 96, 96, 96, 9),       # 82 944 pixels: several tiles per workgroup, partial last tile in every range
+])
+def test_pw_kernel_shapes_and_bit_identity_with_ring_kernel(cin, cout, H, W, B):
+    """Against torch, and BIT-IDENTICAL to conv_dmap (same MFMA, same K order, same epilogue arithmetic)."""
+    dtype = "f16"
+    rng = np.random.default_rng(cin + 3 * cout + H)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    for act in (True, False):
+        y1 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 1, 1, act, None, B, H, W, impl=3, opts={"pw": 1})
+        y0 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 1, 1, act, None, B, H, W, impl=3, opts={"pw": 0})
+        assert rel_err(y1, ref_conv(x, w, b, 1, act)) < TOL[dtype]
+        assert np.array_equal(y1, y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c0,c1,up", [(576, 384, 1), (192, 384, 0), (384, 192, 1), (64, 32, 0)])
+def test_pw_concat_upsample(c0, c1, up):
+    """cat(upsample(a), b) and cat(a, b) as address arithmetic (FPN layers 12, 15, 18, 21), bit-identical to the ring kernel."""
+    dtype = "f16"
+    rng = np.random.default_rng(13 + c0)
+    B, H, W, cout = 3, 12, 20, 192
+    x0 = q(rng.standard_normal((B, H // 2, W // 2, c0) if up else (B, H, W, c0)).astype(np.float32), dtype)
+    x1 = q(rng.standard_normal((B, H, W, c1)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, c0 + c1, 1, 1)) / np.sqrt(c0 + c1)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    srcs = [(c0, 0, c0, up), (c1, 0, c1, 0)]
+    y1 = run_conv(dtype, [x0, x1], w, b, srcs, 1, 1, True, None, B, H, W, impl=3, opts={"pw": 1})
+    y0 = run_conv(dtype, [x0, x1], w, b, srcs, 1, 1, True, None, B, H, W, impl=3, opts={"pw": 0})
+    x0u = np.repeat(np.repeat(x0, 2, 1), 2, 2) if up else x0
+    assert rel_err(y1, ref_conv(np.concatenate([x0u, x1], -1), w, b, 1, True)) < TOL[dtype]
+    assert np.array_equal(y1, y0)
+
+
+@pytest.mark.gpu
+def test_pw_channel_slices_and_untouched_channels():
+    """input = channels 96..287 of a 384-channel buffer (a C2f's branches), output into channels 192..383 of a 576-channel one."""
+    dtype = "f16"
+    rng = np.random.default_rng(83)
+    B, H, W, ld, off, cin, cout = 2, 20, 20, 384, 96, 192, 192
+    x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 1, 1, True, None, B, H, W, dst_ld=576, dst_off=192, impl=3, opts={"pw": 1})
+    y0 = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 1, 1, True, None, B, H, W, dst_ld=576, dst_off=192, impl=3, opts={"pw": 0})
+    assert rel_err(y[..., 192:384], ref_conv(x[..., off:off + cin], w, b, 1, True)) < TOL[dtype]
+    assert np.all(y[..., :192] == 7.0) and np.all(y[..., 384:] == 7.0)
+    assert np.array_equal(y, y0)
