@@ -108,6 +108,7 @@ struct ConvArgs {
   const float* qscale;
   const float* bias_init;
   float out_inv_scale, res_scale;
+  int32_t pair8;                    // conv_dmap.h: 8-channel (16-byte) f16 stores over channel-tile pairs (set by launch_conv_dmap)
 };
 
 // Shared conv epilogue tail: residual add (after the activation, as Bottleneck does) and the store

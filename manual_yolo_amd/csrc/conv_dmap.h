@@ -79,6 +79,13 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   constexpr int XI = BM / 64;
   constexpr int STAGE = ROWS * ROW_BYTES;
   constexpr int NST = dmap_stages<WC, TC>();   // ring slots: 3 (two steps ahead), 2 for the 192-channel tile
+  // f16 outputs with 8-channel aligned views (a.pair8, set by launch_conv_dmap): weight rows are dealt to MFMA rows so that a
+  // lane holds 8 CONSECUTIVE channels of a pixel over a pair of channel tiles -> one 16-byte store per pair and pixel tile
+  // instead of two 8-byte ones: 16 rows x 64 B per store instruction instead of 16 x 32 B.  Same arithmetic per output:
+  // results do not change.  In isolation the 32-byte pieces write at 4.4-5.5 TB/s, the 64-byte ones at 5.7-6.4
+  // (tools/probes/probe_store_patterns.hip, profiles/r03_probe_store_patterns.log).
+  constexpr int NPAIRW = (sizeof(T) == 2) ? TC / 2 : 0;
+  const bool pair8 = NPAIRW > 0 && a.pair8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -194,7 +201,13 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NI - XI; ++i) {
-      const int row = 8 * (wave + 8 * i) + rsub, n = n0 + row;
+      const int row = 8 * (wave + 8 * i) + rsub;
+      int nrow = row;
+      if (pair8) {                       // the MFMA-row deal of conv_h2.h within each wave's TC channel tiles: a lane ends up with
+        const int ti = row >> 4, rho = row & 15, w = ti / TC, iw = ti - w * TC;      // 8 consecutive channels over a tile pair
+        if (iw < 2 * NPAIRW) nrow = (w * TC) * 16 + 32 * (iw >> 1) + 8 * (rho >> 2) + 4 * (iw & 1) + (rho & 3);
+      }
+      const int n = n0 + nrow;
       woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cg * 16) : kOob;
     }
   };
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   constexpr bool DEFER_CT = MIYOLO_DMAP_DEFER && NST > 2;
   constexpr int NP = TC * TPW;                               // pieces per tile
   f32x4 eacc[DEFER_CT ? TC : 1][DEFER_CT ? TPW : 1];
-  const bool defer = DEFER_CT && a.vec_ok && !a.res;         // wave-uniform, constant for the launch
+  const bool defer = DEFER_CT && a.vec_ok && !a.res && !pair8;   // wave-uniform, constant for the launch
   const int ppk = (NP + a.nk - 1) / a.nk;                    // pieces per K step so that a tile's pieces finish within the next tile
   int e_next = NP, e_m0 = 0, e_n0 = 0;                       // next piece to run (NP = nothing pending)
   auto piece_ij = [&](auto ic, auto jc) __attribute__((always_inline)) {
@@ -510,10 +523,10 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       // here would make the compiler wait vmcnt(0) and drain the next tile's DMAs in flight.
       // The bias array is padded to a multiple of 128 floats by the host (weights.py).
       const float* __restrict__ bias = a.bias;
-      auto run_epilogue = [&](auto outf32_tag) {
+      auto run_epilogue_tiles = [&](auto outf32_tag, auto first_tag) {
         constexpr bool OUTF32 = decltype(outf32_tag)::value;
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
+        for (int i = decltype(first_tag)::value; i < TC; ++i) {
           const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + i) * 16);
           const int n = nt + fq * 4;
           // 16 consecutive biases of this 16-channel tile, in SGPRs.  A channel tile that lies wholly beyond cout (the last
@@ -555,6 +568,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
           }
         }
       };
+      auto run_epilogue = [&](auto outf32_tag) { run_epilogue_tiles(outf32_tag, std::integral_constant<int, 0>{}); };
       if (defer) {
         if constexpr (DEFER_CT) {
 #pragma unroll
@@ -562,6 +576,61 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) { eacc[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
           e_m0 = m0; e_n0 = n0; e_next = 0;
+        }
+      } else if (pair8) {
+        if constexpr (NPAIRW > 0) {
+#pragma unroll
+          for (int p = 0; p < NPAIRW; ++p) {
+            const int nt = __builtin_amdgcn_readfirstlane(n0 + (wc * TC + 2 * p) * 16);
+            const int n = nt + fq * 8;
+            // 32 consecutive biases in SGPRs (cout % 16 == 0 and the array is padded to a multiple of 128 floats: nt + 32 never
+            // passes the padding; a pair wholly beyond cout loads pair 0 - see the note at the 16-channel form below)
+            v4i_t s0, s1, s2, s3, s4, s5, s6, s7;
+            const float* bp = sgpr_ptr(bias + (nt < a.cout ? nt : 0));
+            asm volatile("s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\ts_load_dwordx4 %2, %8, 0x20\n\t"
+                         "s_load_dwordx4 %3, %8, 0x30\n\ts_load_dwordx4 %4, %8, 0x40\n\ts_load_dwordx4 %5, %8, 0x50\n\t"
+                         "s_load_dwordx4 %6, %8, 0x60\n\ts_load_dwordx4 %7, %8, 0x70\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(s5), "=&s"(s6), "=&s"(s7) : "s"(bp));
+            float blo[4], bhi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              blo[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s2[r] : fq == 2 ? s4[r] : s6[r]);
+              bhi[r] = __int_as_float(fq == 0 ? s1[r] : fq == 1 ? s3[r] : fq == 2 ? s5[r] : s7[r]);
+            }
+            v4ie_t rv[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) rv[j] = (v4ie_t){0, 0, 0, 0};
+            if (a.res) {                   // wave-uniform: the residual loads of this channel pair in flight together
+#pragma unroll
+              for (int j = 0; j < TPW; ++j) {
+                const int m = m0 + (wp * TPW + j) * 16 + frow;
+                const uint32_t ro = (m < a.M && n < a.cout) ? (uint32_t)((m * a.res_ld + a.res_choff + n) * 2) : kOob;
+                rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+              const int m = m0 + (wp * TPW + j) * 16 + frow;
+              float v[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float x0 = acc[2 * p][j][r] + blo[r], x1 = acc[2 * p + 1][j][r] + bhi[r];
+                if (a.act) { x0 = silu_fast(x0); x1 = silu_fast(x1); }
+                v[r] = x0; v[4 + r] = x1;
+              }
+              if (a.res) {
+                const f16x8 hr = *reinterpret_cast<const f16x8*>(&rv[j]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
+              }
+              const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+              const uint32_t so = (m < a.M && n < a.cout) ? (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2) : kOob;
+              if (!ABL(8)) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, MIYOLO_ST_AUX);
+              acc[2 * p][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[2 * p + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+          if constexpr (TC & 1) run_epilogue_tiles(std::false_type{}, std::integral_constant<int, TC - 1>{});
+          v_stores += (ABL(8) ? 0 : (NPAIRW + (TC & 1)) * TPW);
         }
       } else if (a.vec_ok) {
         if (a.out_f32) run_epilogue(std::true_type{}); else run_epilogue(std::false_type{});
@@ -681,11 +750,14 @@ inline ConvCfg pick_dmap_cfg(int cout, long M, int ncu) {
 }
 
 template <typename T>
-inline hipError_t launch_conv_dmap(const ConvArgs& a, hipStream_t s, int ncu, int force_wc = 0, int force_tc = 0) {
+inline hipError_t launch_conv_dmap(const ConvArgs& a, hipStream_t s, int ncu, int force_wc = 0, int force_tc = 0, int pair8 = 1) {
   ConvCfg c = pick_dmap_cfg(a.cout, a.M, ncu);
   if (force_wc > 0 && force_tc > 0) c = {force_wc, force_tc};
-  if (a.ksize == 3) return launch_dmap_ks<T, 3>(a, c, s, ncu);
-  return launch_dmap_ks<T, 1>(a, c, s, ncu);
+  ConvArgs b = a;
+  b.pair8 = (pair8 && sizeof(T) == 2 && !a.out_f32 && a.vec_ok && a.cout % 16 == 0 && a.dst_ld % 8 == 0 && a.dst_choff % 8 == 0 &&
+             (!a.res || (a.res_ld % 8 == 0 && a.res_choff % 8 == 0))) ? 1 : 0;
+  if (a.ksize == 3) return launch_dmap_ks<T, 3>(b, c, s, ncu);
+  return launch_dmap_ks<T, 1>(b, c, s, ncu);
 }
 
 }  // namespace miyolo

@@ -77,6 +77,7 @@ struct miyolo_engine {
   int h2_warm = 0;          // ... 1: persistent form (next tile's slab issued inside the epilogue): measured 1.4 % SLOWER on the step, off
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
   int pw = 0;               // 1: conv_impl 3, f16: eligible 1x1 layers on the streaming kernel (conv_pw.h) - round-3 experiment, 6-8 % slower than the ring kernel: off
+  int pair8 = 1;            // conv_dmap.h: 16-byte f16 stores over channel-tile pairs (0: 8-byte stores; same results)
   int h3 = 2;               // conv_impl 3, f16: 3x3 stride-1 layers on the three-workgroups-per-CU form of the halo-slab kernel (conv_h3.h):
                             // 0 never, 1 wherever eligible, 2 (default) where its tile count fills the chip better (h3_preferred)
   int h3_min_util = 75;     // ... and its 128-pixel tiles cover at least this share of the map
@@ -437,7 +438,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
         if (h->conv_impl != 3 && h->conv_impl != 8) return fail(h, MIYOLO_ERR_UNSUPPORTED, "fp8 runs on conv_impl 3 / 8 only");
         if ((h->conv_impl == 8 || (h->h2 && h->force_wc == 0)) && h2_eligible<T>(a, h->conv_impl == 8 ? 0.0 : 0.01 * h->h2_min_util))
           HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
-        else HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+        else HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc, h->pair8));
       } else {
       bool done_h3 = false;
       if constexpr (sizeof(T) == 2) {
@@ -469,7 +470,7 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       else if (sizeof(T) == 2 && h->conv_impl == 3 && h->pw && h->force_wc == 0 && pw_eligible(a)) {
         HIP_TRY(h, launch_conv_pw(a, s, h->ncu));
       }
-      else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc));
+      else if (h->conv_impl >= 3) HIP_TRY(h, launch_conv_dmap<T>(a, s, h->ncu, h->force_wc, h->force_tc, h->pair8));
       else if (h->conv_impl >= 1) HIP_TRY(h, launch_conv_dma<T>(a, s, h->force_wc, h->force_tc));
       else HIP_TRY(h, launch_conv<T>(a, s, h->force_wc, h->force_tc));
       }
@@ -1227,6 +1228,7 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
   if (!strcmp(key, "pw")) { h->pw = value; return 0; }
+  if (!strcmp(key, "pair8")) { h->pair8 = value; return 0; }
   if (!strcmp(key, "h3")) { h->h3 = value; return 0; }
   if (!strcmp(key, "h3_min_util")) { h->h3_min_util = value; return 0; }
   if (!strcmp(key, "h3_max_w")) { h->h3_max_w = value; return 0; }

@@ -391,3 +391,47 @@ def test_pw_channel_slices_and_untouched_channels():
     assert rel_err(y[..., 192:384], ref_conv(x[..., off:off + cin], w, b, 1, True)) < TOL[dtype]
     assert np.all(y[..., :192] == 7.0) and np.all(y[..., 384:] == 7.0)
     assert np.array_equal(y, y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,k,s,H,W,B,res,force", [
+    (96, 96, 1, 1, 16, 16, 2, False, None),       # BN = 96 as 2 waves x 3 tiles: one pair + one unpaired tile per wave
+    (192, 192, 1, 1, 16, 16, 2, False, None),     # 256 x 192 tile: three pairs per wave
+    (64, 128, 3, 2, 32, 32, 2, False, (2, 4)),    # stride-2 3x3, two pairs per wave
+    (48, 96, 3, 2, 32, 32, 2, False, None),       # model.1's shape class
+    (64, 64, 3, 1, 12, 12, 3, True, (1, 4)),      # 8 x 1 wave layout (32-pixel wave tiles), residual read 16 bytes at a time
+    (32, 32, 1, 1, 10, 10, 2, True, (1, 2)),      # one pair, residual
+    (64, 80, 1, 1, 10, 10, 2, False, (1, 3)),     # cout = 80: channel tail inside a pair (channels 80..95 do not exist)
+    (64, 16, 1, 1, 10, 10, 2, False, (1, 1)),     # one channel tile: nothing to pair
+])
+def test_dmap_paired_stores_change_no_bit(cin, cout, k, s, H, W, B, res, force):
+    """conv_dmap.h option pair8 (default 1): weight rows dealt so that a lane holds 8 consecutive channels over a channel-tile pair,
+    one 16-byte store per pair - against torch, and bit-identical to the 8-byte-store form."""
+    dtype = "f16"
+    rng = np.random.default_rng(cin * 5 + cout + k)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H // s, W // s, cout)).astype(np.float32), dtype) if res else None
+    kw = dict(force=force, impl=3, opts={"h2": 0, "t2d": 0, "pair8": 1})
+    y1 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, r, B, H, W, **kw)
+    kw["opts"] = {"h2": 0, "t2d": 0, "pair8": 0}
+    y0 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], k, s, True, r, B, H, W, **kw)
+    assert rel_err(y1, ref_conv(x, w, b, s, True, r)) < TOL[dtype]
+    assert np.array_equal(y1, y0)
+
+
+@pytest.mark.gpu
+def test_dmap_paired_stores_channel_slices():
+    """8-aligned slices use the paired stores and leave the neighbours alone; a 4-aligned destination falls back to 8-byte stores."""
+    dtype = "f16"
+    rng = np.random.default_rng(97)
+    B, H, W, ld, off, cin, cout = 2, 12, 12, 192, 96, 96, 96
+    x = q(rng.standard_normal((B, H, W, ld)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = ref_conv(x[..., off:off + cin], w, b, 1, True)
+    for dst_off in (96, 100):
+        y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 1, 1, True, None, B, H, W, dst_ld=288, dst_off=dst_off, impl=3)
+        assert rel_err(y[..., dst_off:dst_off + cout], ref) < TOL[dtype]
+        assert np.all(y[..., :dst_off] == 7.0) and np.all(y[..., dst_off + cout:] == 7.0)
