@@ -1,16 +1,20 @@
 // The stem and the first down-sampling conv as ONE launch (f16): uint8 frame -> conv3x3 s2 (3 -> C0) + SiLU -> conv3x3 s2
 // (C0 -> C1) + SiLU, yolov8's layers 0 and 1 (reference: `model(frame)`, detect.py:541 -> [3P] DetectionModel layers 0, 1).
 //
-// Why (profiles/r02_per_layer_f16.md): the stem writes its 320 x 320 x 48 map (629 MB at batch 64) to HBM at 2.6 TB/s and
-// layer 1 reads it back through the ring kernel at 3 TB/s: 274 + 316 us for 79 MB of frames in and 315 MB of activations
-// out.  Here a persistent workgroup keeps layer 1's weights in LDS (96 x 432 halves = 86 KiB), computes the 17 x 33 patch of
-// the stem's output that an 8 x 16 tile of layer 1 needs straight from the frame into LDS (zero outside the stem's map:
-// layer 1's padding; 10 % of the stem is computed twice), and runs layer 1 on it.  The stem's map never touches HBM.
+// Why (profiles/r03_per_layer_f16.md): the stem writes its 320 x 320 x 48 map (629 MB at batch 64) to HBM and layer 1 reads
+// it back through the ring kernel at 3 TB/s: 242 + 316 us for 79 MB of frames in and 315 MB of activations out.  Here a
+// persistent workgroup keeps layer 1's weights in LDS (96 x 432 halves = 87 KiB), computes the 17 x 17 patch of the stem's
+// output that an 8 x 8 tile of layer 1 needs straight from the frame into LDS (zero outside the stem's map: layer 1's
+// padding; 13 % of the stem is computed twice), and runs layer 1 on it.  The stem's map never touches HBM.
 // Arithmetic is that of stem_kernel (same K' order, same 1/255 scaling, same f16 rounding of its output) followed by that
 // of the ring / 2-D-tile kernels (flattened K = (tap, channel) ascending): bit-identical to the two launches.
-// MEASURED: no gain (8 620-8 690 vs 8 650-8 705 frames/s A/B) - with one workgroup per CU the stem phase (frame bytes through
-// the texture path, 27 k SiLUs per tile) and layer 1's K loop (one pixel tile per wave: 7 KiB of LDS fragments per 6 MFMAs)
-// take turns instead of overlapping, which costs what the saved HBM traffic gains.  Off by default (option stem_fuse).
+// Round 2's form (one 8 x 16 tile at a time, all eight waves in the same phase) measured no gain: with one workgroup per CU
+// the stem phase (frame bytes through the texture path as single-byte loads, 27 k SiLUs per tile: VALU) and layer 1's K
+// loop (LDS fragments + MFMA) took turns - 25 k cycles per tile, 518 us.  Round 3: the workgroup is TWO GROUPS of four waves
+// on two tiles, one phase apart - while group 0 computes the stem patch of its tile, group 1 runs layer 1 on the patch
+// it finished in the previous phase, and vice versa; one workgroup barrier per phase.  Every SIMD hosts one wave of each
+// group, so its VALU (stem: conversions, SiLU) and its LDS / matrix pipes (layer 1) work at the same time.  The frame bytes
+// come as one 12-byte load per lane (stem_kernel's round-3 gather) issued a phase ahead.
 #pragma once
 #include "common.h"
 #include "conv_dma.h"
@@ -30,15 +34,15 @@ struct Stem2Args {
   uint32_t mg_img_mul, mg_img_shift, mg_tx_mul, mg_tx_shift;
 };
 
-constexpr int kS2Oh = 8, kS2Ow = 16;                        // output tile of layer 1
-constexpr int kS2Sh = 2 * kS2Oh + 1, kS2Sw = 2 * kS2Ow + 1;  // the stem pixels it reads: 17 x 33
+constexpr int kS2Oh = 8, kS2Ow = 8;                         // output tile of layer 1 (per wave group)
+constexpr int kS2Sh = 2 * kS2Oh + 1, kS2Sw = 2 * kS2Ow + 1;  // the stem pixels it reads: 17 x 17
 
 template <int TCS, int TC1> struct Stem2Geo {
   static constexpr int C0 = TCS * 16, C1 = TC1 * 16, SROW = C0 * 2, CPT = C0 / 8, NCH = 9 * CPT, NG = (NCH + 3) / 4, WROW = NG * 64 + 32;   // pitch = 2 (mod 4) chunks: conflict-free weight fragments (conv_bneck.h)
-  static constexpr int NSPX = kS2Sh * kS2Sw, NST = (NSPX + 15) / 16, TPW = (NST + 7) / 8;     // stem pixels, their 16-pixel tiles, tiles per wave
+  static constexpr int NSPX = kS2Sh * kS2Sw, NST = (NSPX + 15) / 16, TPW = (NST + 3) / 4;     // stem pixels, their 16-pixel tiles, tiles per wave of a group
   static constexpr int W_BYTES = C1 * WROW, KOFF_BYTES = NG * 16;
-  static constexpr int S_OFF = W_BYTES + KOFF_BYTES, S_BYTES = NSPX * SROW;
-  static constexpr int LDS = S_OFF + S_BYTES;
+  static constexpr int S_OFF = W_BYTES + KOFF_BYTES, S_BYTES = (NSPX * SROW + 255) / 256 * 256;   // one patch per group
+  static constexpr int LDS = S_OFF + 2 * S_BYTES;
 };
 
 template <int TCS, int TC1>
@@ -48,25 +52,28 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wg = wave & 3;                  // wave group (its own tile and patch), wave within it
   const int frow = lane & 15, fq = lane >> 4;
   unsigned char* const wl = smem;
   int32_t* const koff = reinterpret_cast<int32_t*>(smem + G::W_BYTES);
-  unsigned char* const sl = smem + G::S_OFF;
+  unsigned char* const sl = smem + G::S_OFF + grp * G::S_BYTES;
 
   const int Gd = gridDim.x;
   const int first = (blockIdx.x & 7) * (Gd >> 3) + (blockIdx.x >> 3);
   const int my_tiles = (first < a.ntiles) ? (a.ntiles - first + Gd - 1) / Gd : 0;
   if (my_tiles == 0) return;
+  const int nk = (my_tiles - grp + 1) / 2;                   // tiles of this group: the workgroup's tiles grp, grp + 2, ...
+  const int phases = max(2 * ((my_tiles + 1) / 2), 2 * (my_tiles / 2) + 1);      // group 0: stem at 2k, conv at 2k+1; group 1 one later
 
   // ---- layer 1's weights and its tap table -> LDS, once per workgroup
   {
     const int cpr = NG * 4;
     const size_t row_bytes = (size_t)a.kpad * 2;
-    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w1);
+    const unsigned char* wgp = reinterpret_cast<const unsigned char*>(a.w1);
     for (int e = tid; e < G::C1 * cpr; e += 512) {
       const int n = e / cpr, c = e - n * cpr;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if ((size_t)(c + 1) * 16 <= row_bytes) v = *reinterpret_cast<const uint4*>(wg + (size_t)n * row_bytes + c * 16);
+      if ((size_t)(c + 1) * 16 <= row_bytes) v = *reinterpret_cast<const uint4*>(wgp + (size_t)n * row_bytes + c * 16);
       *reinterpret_cast<uint4*>(wl + n * WROW + c * 16) = v;
     }
     for (int q = tid; q < NG * 4; q += 512) {
@@ -96,62 +103,66 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.in), 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst_bytes, 0x00020000);
   const int Hs = a.H / 2, Ws = a.W / 2, Ho = a.H / 4, Wo = a.W / 4;
-  // stem_kernel's per-lane byte pattern: q < 3: row hi0 + q, bytes j of the 9-byte run from column wi0; q == 3: rows hi0 + j, byte 8
-  const int W3 = a.W * 3;
-  const int startq = (fq < 3) ? fq * W3 : 8, stepq = (fq < 3) ? 1 : W3;
-  const uint32_t m_always = (fq < 3) ? 0u : 0xF8u, m_top = (fq < 3) ? (fq == 0 ? 0xFFu : 0u) : 1u, m_left = (fq < 3) ? 7u : 0u;
-  // this wave's stem pixels: tiles wave, wave + 8, ...
+  // this wave's stem pixels: 16-pixel tiles wg, wg + 4, ... of the group's 17 x 17 patch
   int sy[TPW], sx[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
-    const int ps = (wave + 8 * j) * 16 + frow;
+    const int ps = (wg + 4 * j) * 16 + frow;
     sy[j] = (ps < G::NSPX) ? ps / kS2Sw : -10000;
     sx[j] = ps % kS2Sw;
   }
   uint32_t abase[TC1];
 #pragma unroll
   for (int i = 0; i < TC1; ++i) abase[i] = (uint32_t)((i * 16 + frow) * WROW + fq * 16);
-  const int bbase = ((2 * wave) * kS2Sw + 2 * frow) * SROW;          // output pixel (wave, frow) of the tile, tap (0, 0)
+  // layer 1: this wave's 16 output pixels = rows 2 wg, 2 wg + 1 of the 8 x 8 tile; tap (0, 0) of pixel (oy, ox) is patch pixel (2 oy, 2 ox)
+  const int oy_l = 2 * wg + (frow >> 3), ox_l = frow & 7;
+  const int bbase = ((2 * oy_l) * kS2Sw + 2 * ox_l) * SROW;
 
   auto tile_coords = [&](int tile, int* b, int* ty, int* tx) {
     const uint32_t bb = magic_div((uint32_t)tile, a.mg_img_mul, a.mg_img_shift);
     const uint32_t r = (uint32_t)tile - bb * (uint32_t)(a.tiles_x * a.tiles_y);
     *ty = (int)magic_div(r, a.mg_tx_mul, a.mg_tx_shift); *tx = (int)r - *ty * a.tiles_x; *b = (int)bb;
   };
-  // the frame bytes of this wave's stem pixels for `tile` (the next tile's are in flight under layer 1's K loop)
-  auto fetch = [&](int tile, uint32_t (&u)[TPW][8]) {
+  // Frame bytes of this wave's stem pixels (stem_kernel's gather): lane (pixel, q < 3) loads the 12 bytes around the 9-byte run of
+  // window row q; cut out and handed to the q = 3 lanes at consumption.  Issued a phase ahead (under layer 1's K loop).
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b96(rin, 0u, 0, 0)) v3u_t;
+  auto window_off = [&](int b, int ty, int tx, int j, bool* vm, bool* left, bool* rowok) -> int {
+    const int gy = 2 * ty * kS2Oh - 1 + sy[j], gx = 2 * tx * kS2Ow - 1 + sx[j];          // stem-map coordinates
+    *vm = gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+    *left = gx == 0;
+    *rowok = *vm && fq < 3 && !(gy == 0 && fq == 0);
+    return ((b * a.H + 2 * gy - 1 + (fq < 3 ? fq : 0)) * a.W + 2 * gx - 1) * 3 + (*left ? 3 : 0);
+  };
+  auto fetch = [&](int tile, v3u_t (&u)[TPW]) {
     int b, ty, tx;
     tile_coords(tile, &b, &ty, &tx);
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      const int gy = 2 * ty * kS2Oh - 1 + sy[j], gx = 2 * tx * kS2Ow - 1 + sx[j];
-      const bool vm = gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
-      const int rb = ((b * a.H + 2 * gy - 1) * a.W + 2 * gx - 1) * 3;
-      const uint32_t inval = (vm ? m_always : 0xFFu) | (gy == 0 ? m_top : 0u) | (gx == 0 ? m_left : 0u);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t off = (uint32_t)(rb + startq + k * stepq) | (((inval >> k) & 1u) << 31);
-        u[j][k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rin, off, 0, 0);
-      }
+      bool vm, left, rowok;
+      const int o = window_off(b, ty, tx, j, &vm, &left, &rowok);
+      u[j] = __builtin_amdgcn_raw_buffer_load_b96(rin, rowok ? ((uint32_t)o & ~3u) : 0x80000000u, 0, 0);
     }
   };
-
-  __syncthreads();
-  uint32_t un[TPW][8];
-  fetch(first, un);
-  int tile = first;
-  for (int t = 0; t < my_tiles; ++t, tile += Gd) {
+  auto stem_phase = [&](int tile, const v3u_t (&u)[TPW]) {
     int b, ty, tx;
     tile_coords(tile, &b, &ty, &tx);
-    // ---- stem on this wave's pixels -> S (f16, zero outside the stem's map)
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      const int ps = (wave + 8 * j) * 16 + frow;
-      const int gy = 2 * ty * kS2Oh - 1 + sy[j], gx = 2 * tx * kS2Ow - 1 + sx[j];
-      const bool vm = gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+      const int ps = (wg + 4 * j) * 16 + frow;
+      bool vm, left, rowok;
+      const int o = window_off(b, ty, tx, j, &vm, &left, &rowok);
+      const uint32_t sh = (uint32_t)o & 3u;
+      uint32_t lo = __builtin_amdgcn_alignbyte((uint32_t)u[j][1], (uint32_t)u[j][0], sh);
+      uint32_t hi = __builtin_amdgcn_alignbyte((uint32_t)u[j][2], (uint32_t)u[j][1], sh);
+      uint32_t b8 = ((uint32_t)u[j][2] >> (8u * sh)) & 0xFFu;
+      if (left) { b8 = (hi >> 8) & 0xFFu; hi = (hi << 24) | (lo >> 8); lo = lo << 24; }
+      const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(frow * 4, (int)b8);
+      const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((frow + 16) * 4, (int)b8);
+      const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((frow + 32) * 4, (int)b8);
+      if (fq == 3) { lo = r0 | (r1 << 8) | (r2 << 16); hi = 0u; }
       f16x8 xb;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) xb[k] = (half_t)((float)un[j][k] * (1.0f / 255.0f));
+      for (int k = 0; k < 8; ++k) xb[k] = (half_t)((float)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xFFu) * (1.0f / 255.0f));
 #pragma unroll
       for (int tc = 0; tc < TCS; ++tc) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -169,45 +180,73 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
         }
       }
     }
-    __syncthreads();                                         // S complete
-    if (t + 1 < my_tiles) fetch(tile + Gd, un);
-    // ---- layer 1 on the patch: one 16-pixel tile (row `wave` of the 8 x 16 output tile) x all channels per wave
+  };
+  auto conv_phase = [&](int tile) {
+    int b, ty, tx;
+    tile_coords(tile, &b, &ty, &tx);
     f32x4 acc1[TC1];
 #pragma unroll
     for (int i = 0; i < TC1; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+    // software pipeline: K group kg + 1's seven fragments are read before kg's six MFMAs are issued (a wave has ONE pixel tile:
+    // left to the compiler each group's reads wait behind the previous group's MFMAs and every group exposes an LDS latency)
+    uint4 bfn = *reinterpret_cast<const uint4*>(sl + bbase + koff[fq]), afn[TC1];
+#pragma unroll
+    for (int i = 0; i < TC1; ++i) afn[i] = *reinterpret_cast<const uint4*>(wl + abase[i]);
+#pragma unroll
     for (int kg = 0; kg < NG; ++kg) {
-      const int ko = koff[kg * 4 + fq];
-      const uint4 bf = *reinterpret_cast<const uint4*>(sl + bbase + ko);
+      const uint4 bf = bfn;
+      uint4 af[TC1];
 #pragma unroll
-      for (int i = 0; i < TC1; ++i) {
-        const uint4 af = *reinterpret_cast<const uint4*>(wl + abase[i] + kg * 64);
-        Mma<half_t>::run(af, bf, acc1[i]);
+      for (int i = 0; i < TC1; ++i) af[i] = afn[i];
+      if (kg + 1 < NG) {
+        bfn = *reinterpret_cast<const uint4*>(sl + bbase + koff[(kg + 1) * 4 + fq]);
+#pragma unroll
+        for (int i = 0; i < TC1; ++i) afn[i] = *reinterpret_cast<const uint4*>(wl + abase[i] + (kg + 1) * 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TC1; ++i) Mma<half_t>::run(af[i], bf, acc1[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int m = (b * Ho + ty * kS2Oh + oy_l) * Wo + tx * kS2Ow + ox_l;
+#pragma unroll
+    for (int i = 0; i < TC1; ++i) {
+      const int n = i * 16 + fq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc1[i][r] + b1v[i][r];
+        if (a.act1) x = silu_fast(x);
+        v[r] = x;
+      }
+      const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2), 0, 0);
+    }
+  };
+
+  // ---- phases: group g computes the stem patch of its k-th tile in phase 2k + g and runs layer 1 on it in phase 2k + g + 1
+  v3u_t un[TPW];
+  if (nk > 0) fetch(first + grp * Gd, un);
+  __syncthreads();                                           // weights and tap table in place
+  for (int p = 0; p < phases; ++p) {
+    const int q = p - grp;
+    const int k = q >> 1;
+    if (q >= 0 && k < nk) {                                  // wave-uniform
+      const int tile = first + (2 * k + grp) * Gd;
+      if (!(q & 1)) {
+        stem_phase(tile, un);
+      } else {
+        if (k + 1 < nk) fetch(tile + 2 * Gd, un);            // the next patch's frame bytes fly under this K loop
+        conv_phase(tile);
       }
     }
-    {
-      const int m = (b * Ho + ty * kS2Oh + wave) * Wo + tx * kS2Ow + frow;
-#pragma unroll
-      for (int i = 0; i < TC1; ++i) {
-        const int n = i * 16 + fq * 4;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc1[i][r] + b1v[i][r];
-          if (a.act1) x = silu_fast(x);
-          v[r] = x;
-        }
-        const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2), 0, 0);
-      }
-    }
-    __syncthreads();                                         // S free again
+    __syncthreads();
   }
 }
 
 // host side ------------------------------------------------------------------------------------------------------
 inline bool stem2_shape_ok(int C0, int C1, int H, int W, size_t* lds) {
-  if (H % (4 * kS2Oh) || W % (4 * kS2Ow)) return false;
+  if (H % (4 * kS2Oh) || W % (4 * kS2Ow)) return false;           // whole 8 x 8 tiles of layer 1's map
   if (C0 == 48 && C1 == 96) *lds = Stem2Geo<3, 6>::LDS;
   else if (C0 == 16 && C1 == 32) *lds = Stem2Geo<1, 2>::LDS;
   else if (C0 == 32 && C1 == 64) *lds = Stem2Geo<2, 4>::LDS;

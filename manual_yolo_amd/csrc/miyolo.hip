@@ -102,7 +102,7 @@ struct miyolo_engine {
   int batch_split = 0;      // detect: K > 1 runs a single-chunk batch as K part batches on K streams (measured +0.8..1.4 %, off)
   std::vector<hipStream_t> split_streams;
   std::vector<hipEvent_t> split_ev;   // [0] fork, [k] join of part k
-  int stem_fuse = 0;        // the stem and the first stride-2 conv as one launch (conv_stem2.h), f16: measured no gain, off
+  int stem_fuse = 1;        // f16: the stem and the first stride-2 conv as one launch (conv_stem2.h; round 3: two wave groups a phase apart, 558 -> 342 us)
   int bneck_fuse = 1;       // a narrow Bottleneck's two 3x3 convs as one launch (conv_bneck.h), f16
   int sppf_fuse = 1;        // three chained MAXPOOL5 ops (SPPF) as one launch (sppf3_kernel)
   int fuse_pre = 0;         // set by miyolo_detect around run_ops: the decode op also runs the NMS score filter

@@ -121,7 +121,7 @@ def _materialise_all(eng):
     keep the first op's output in LDS: its buffer in the workspace is never written (round-2 ADVICE: calibration read uninitialised memory for
     yolov8m's model.2.m.*.cv1 - garbage scales for two layers).  Switch those fusions off while taps are read; returns a
     function that restores the options.  (miyolo_read_buffer now also refuses such a buffer.)"""
-    prev = {k: eng.options.get(k, d) for k, d in (("bneck_fuse", 1), ("stem_fuse", 0), ("cls_mega", 1))}
+    prev = {k: eng.options.get(k, d) for k, d in (("bneck_fuse", 1), ("stem_fuse", 1), ("cls_mega", 1))}
     for k in prev:                       # cls_mega: the one-launch classifier keeps EVERY activation in LDS
         eng.set_option(k, 0)
 
