@@ -50,6 +50,12 @@
 #define MIYOLO_DMAP_EXACT_VMCNT 1
 #endif
 
+// The 256 x 192 tile (2-slot ring): activations and weights in SEPARATE rings - three activation slots (two K steps ahead),
+// two weight slots (one ahead): 144 KiB instead of 112.  See the kernel.
+#ifndef MIYOLO_DMAP_SPLIT
+#define MIYOLO_DMAP_SPLIT 1
+#endif
+
 namespace miyolo {
 
 // Ring depth per tile shape: the 256 x 192 tile (56 KiB per stage) only fits twice; its steps are twice as
@@ -58,6 +64,8 @@ template <int WC, int TC>
 constexpr int dmap_stages() { return (WC * TC * 16 > 128) ? 2 : 3; }
 template <int WC, int TC>
 constexpr size_t dmap_lds_bytes() {
+  if (MIYOLO_DMAP_SPLIT && dmap_stages<WC, TC>() == 2)
+    return (size_t)(3 * DMA_BM + 2 * ((WC * TC * 16 + 63) / 64 * 64)) * ROW_BYTES;
   return (size_t)dmap_stages<WC, TC>() * (DMA_BM + (WC * TC * 16 + 63) / 64 * 64) * ROW_BYTES;
 }
 
@@ -79,6 +87,13 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   constexpr int XI = BM / 64;
   constexpr int STAGE = ROWS * ROW_BYTES;
   constexpr int NST = dmap_stages<WC, TC>();   // ring slots: 3 (two steps ahead), 2 for the 192-channel tile
+  // SPLIT (the 2-slot shape, round 3): with one ring of two (activations + weights) slots ONE K step is in flight while the
+  // other is computed on, and a step takes what a fill takes (~5.5 k cycles on the HBM-bound 1x1 layers against 1.5 k of
+  // MFMAs).  The weights are L2-resident and need no depth; the activations do.  So: three activation slots (X(c + 2) goes
+  // out in step c) and two weight slots (W(c + 1)); per step the weights are issued FIRST, so that waiting for W(c) and
+  // X(c) leaves exactly the youngest activation stage (XI DMAs per wave) in flight.
+  constexpr bool SPLIT = MIYOLO_DMAP_SPLIT && NST == 2;
+  constexpr int XSTAGE = BM * ROW_BYTES, WSTAGE = BNP * ROW_BYTES, NXS = 3, NWS = 2;
   // f16 outputs with 8-channel aligned views (a.pair8, set by launch_conv_dmap): weight rows are dealt to MFMA rows so that a
   // lane holds 8 CONSECUTIVE channels of a pixel over a pair of channel tiles -> one 16-byte store per pair and pixel tile
   // instead of two 8-byte ones: 16 rows x 64 B per store instruction instead of 16 x 32 B.  Same arithmetic per output:
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   // segment `sel`:   ktab[ks*8 + c] = sel << 28 | kofs.   3x3: sel = tap 0..8, 9 = K tail (the
   // row masks carry a permanently set bit 9); 1x1: sel = segment 0/1, tail = bit 31 of kofs.
   // This replaces a per-step walker (divisions by 3, a divergent carry loop) with one ds_read.
-  uint32_t* const ktab = reinterpret_cast<uint32_t*>(smem + NST * STAGE);
+  uint32_t* const ktab = reinterpret_cast<uint32_t*>(smem + (SPLIT ? NXS * XSTAGE + NWS * WSTAGE : NST * STAGE));
   for (int e = tid; e < a.nk * 8; e += 512) {
     const int q = e;                       // chunk index on the flattened K axis
     uint32_t v;
@@ -157,12 +172,28 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   uint32_t xinv[XI];         // 3x3: bit t = tap t OUTSIDE the image (bit 9 always set); 1x1: 0 / 0x80000000
   uint32_t woff[NI - XI];
   int d_tile = first, d_ks = 0, d_slot = 0, d_issued = 0;
+  int w_tile = first, w_ks = 0, w_slot = 0;            // SPLIT: the weight stream (one step behind the activation stream)
   int v_stores = 0;                      // vector memory ops issued since the last DMA of the youngest stage (wave-uniform)
 
   // Per-lane row state of `tile`.  DMA i of this wave covers rows 8*(wave + 8*i) + (lane >> 3) and the 8 lanes of a
   // row group share a row, so computing per (lane, i) would do every row 8 times over.  Lane L computes ONE row -
   // (i = (L >> 3) & 3, rsub = L & 7) - and the wave transposes with ds_bpermute: DMA i of lane L takes its values
   // from lane 8*i + (L >> 3)  (profiles/r01_ws_kernel.md: the redundant form cost thousands of VALU cycles per tile).
+  auto set_w = [&](int tile) {                         // weight-row offsets of `tile`'s channel tile
+    const int mb = tile / NB, nb = tile - mb * NB;
+    const int n0 = nb * BN;
+#pragma unroll
+    for (int i = 0; i < NI - XI; ++i) {
+      const int row = 8 * (wave + 8 * i) + rsub;
+      int nrow = row;
+      if (pair8) {                       // the MFMA-row deal of conv_h2.h within each wave's TC channel tiles: a lane ends up with
+        const int ti = row >> 4, rho = row & 15, w = ti / TC, iw = ti - w * TC;      // 8 consecutive channels over a tile pair
+        if (iw < 2 * NPAIRW) nrow = (w * TC) * 16 + 32 * (iw >> 1) + 8 * (rho >> 2) + 4 * (iw & 1) + (rho & 3);
+      }
+      const int n = n0 + nrow;
+      woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cg * 16) : kOob;
+    }
+  };
   const int bp_base = (lane >> 3) * 4;
   auto setup_tile = [&](int tile) {
     const int mb = tile / NB, nb = tile - mb * NB;       // wave-uniform: scalar unit
@@ -199,17 +230,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
       xinv[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + i * 32, (int)c_inv);
       if constexpr (KS == 1) xoff1[i] = __builtin_amdgcn_ds_bpermute(bp_base + i * 32, c_off1);
     }
-#pragma unroll
-    for (int i = 0; i < NI - XI; ++i) {
-      const int row = 8 * (wave + 8 * i) + rsub;
-      int nrow = row;
-      if (pair8) {                       // the MFMA-row deal of conv_h2.h within each wave's TC channel tiles: a lane ends up with
-        const int ti = row >> 4, rho = row & 15, w = ti / TC, iw = ti - w * TC;      // 8 consecutive channels over a tile pair
-        if (iw < 2 * NPAIRW) nrow = (w * TC) * 16 + 32 * (iw >> 1) + 8 * (rho >> 2) + 4 * (iw & 1) + (rho & 3);
-      }
-      const int n = n0 + nrow;
-      woff[i] = (row < BN && n < a.cout) ? (uint32_t)(n * a.kpad * (int)sizeof(T) + cg * 16) : kOob;
-    }
+    if constexpr (!SPLIT) set_w(tile);
   };
 
   // L2 warm-up of `tile` (3x3 stride-1, single source): lanes 0-31 of a wave own 32 of the tile's 256 pixels (as in
@@ -289,6 +310,47 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     }
   };
 
+  // SPLIT: the two streams.  issue_x: the activation DMAs of the activation stream's next (tile, K step) into slot d_slot of
+  // three; issue_w: the weight DMAs of the weight stream's next step into slot w_slot of two.
+  auto issue_x = [&]() {
+    const uint32_t st = lds_base + (uint32_t)(d_slot * XSTAGE + wave * 1024);
+    const int ks = d_ks;
+    const uint32_t e = ktab[ks * 8 + cg];
+    if constexpr (KS == 3) {
+      const uint32_t tp = e >> 28, kofs = e & 0x0FFFFFFFu;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) lds_dma16(rs0, st + i * 8192, ((uint32_t)xoff0[i] + kofs) | (((xinv[i] >> tp) & 1u) << 31));
+    } else {
+      const bool seg1 = (ks * 8) >= ct0;
+      const uint32_t kofs = e & 0x8FFFFFFFu;
+      if (!seg1) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) lds_dma16(rs0, st + i * 8192, ((uint32_t)xoff0[i] + kofs) | xinv[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) lds_dma16(rs1, st + i * 8192, ((uint32_t)xoff1[KS == 1 ? i : 0] + kofs) | xinv[i]);
+      }
+    }
+    d_slot = (d_slot == NXS - 1) ? 0 : d_slot + 1;
+    ++d_issued;
+    if (++d_ks == a.nk) {
+      d_ks = 0;
+      d_tile += G;
+      if (d_tile < ntiles) setup_tile(d_tile);
+    }
+  };
+  auto issue_w = [&]() {
+    const uint32_t st = lds_base + (uint32_t)(NXS * XSTAGE + w_slot * WSTAGE + wave * 1024);
+#pragma unroll
+    for (int i = 0; i < NI - XI; ++i) lds_dma16(rsw, st + i * 8192, woff[i] + (uint32_t)(w_ks * 128));
+    w_slot ^= 1;
+    if (++w_ks == a.nk) {
+      w_ks = 0;
+      w_tile += G;
+      if (w_tile < ntiles) set_w(w_tile);
+    }
+  };
+
   f32x4 acc[TC][TPW];
 #pragma unroll
   for (int i = 0; i < TC; ++i)
@@ -296,9 +358,9 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     for (int j = 0; j < TPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
-  auto compute = [&](int slot) {
-    const unsigned char* xs = smem + slot * STAGE;
-    const unsigned char* ws = xs + BM * ROW_BYTES;
+  auto compute = [&](int slot, int wslot = 0) {
+    const unsigned char* xs = smem + slot * (SPLIT ? XSTAGE : STAGE);
+    const unsigned char* ws = SPLIT ? smem + NXS * XSTAGE + wslot * WSTAGE : xs + BM * ROW_BYTES;
     if constexpr (is_fp8<T>::value) {                  // one K = 128 MFMA per (channel tile, pixel tile): chunks q and q + 4
       uint4 af[TC][2], bf[TPW][2];
 #pragma unroll
@@ -468,17 +530,33 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 
   // ---- stream: prologue issues two stages, then one barrier + one issue + one compute per step
   setup_tile(d_tile);
-  issue_next();
-  if (NST > 2 && total_steps > 1) issue_next();
+  if constexpr (SPLIT) {
+    set_w(w_tile);
+    issue_x();                                   // X(0)
+    issue_w();                                   // W(0)
+    if (total_steps > 1) issue_x();              // X(1): the order W(c), X(c + 1) of the loop
+  } else {
+    issue_next();
+    if (NST > 2 && total_steps > 1) issue_next();
+  }
 
-  int c_tile = first, c_ks = 0, c_slot = 0;
+  int c_tile = first, c_ks = 0, c_slot = 0, cw_slot = 0;
 #if MIYOLO_ABLATE
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc_wait = 0, acc_issue = 0, acc_comp = 0, acc_epi = 0, t_begin = 0;
   STAMP(t_begin);
 #endif
   for (int c = 0; c < total_steps; ++c) {
     STAMP(t0);
-    if (NST > 2 && c + 1 < total_steps) {      // one younger stage may stay in flight
+    if (SPLIT && c + 1 < total_steps) {        // X(c + 1) - XI DMAs per wave - and the stores behind it may stay in flight
+#define MIYOLO_WAIT(K) case (K): asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XI + (K)) : "memory"); break;
+      switch (MIYOLO_DMAP_EXACT_VMCNT ? v_stores : 0) {
+        MIYOLO_WAIT(0) MIYOLO_WAIT(1) MIYOLO_WAIT(2) MIYOLO_WAIT(3) MIYOLO_WAIT(4) MIYOLO_WAIT(5) MIYOLO_WAIT(6) MIYOLO_WAIT(7) MIYOLO_WAIT(8)
+        MIYOLO_WAIT(9) MIYOLO_WAIT(10) MIYOLO_WAIT(11) MIYOLO_WAIT(12) MIYOLO_WAIT(13) MIYOLO_WAIT(14) MIYOLO_WAIT(15) MIYOLO_WAIT(16)
+        MIYOLO_WAIT(17) MIYOLO_WAIT(18) MIYOLO_WAIT(19) MIYOLO_WAIT(20) MIYOLO_WAIT(21) MIYOLO_WAIT(22) MIYOLO_WAIT(23) MIYOLO_WAIT(24)
+        default: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XI) : "memory"); break;   // uncounted: conservative
+      }
+#undef MIYOLO_WAIT
+    } else if (!SPLIT && NST > 2 && c + 1 < total_steps) {      // one younger stage may stay in flight
       // vmcnt counts loads, stores and LDS-DMAs together, in issue order: what may stay outstanding is the youngest
       // stage's NI DMAs PLUS the epilogue stores issued after them (v_stores).  Waiting for fewer would wait for those
       // DMAs themselves - a full DMA latency per step (measured: 2.3x slower with one store per step unaccounted).
@@ -502,6 +580,12 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     if constexpr (MIYOLO_DMAP_INTERLEAVE && (NST > 2 || MIYOLO_DMAP_INTERLEAVE > 1)) {      // measured: -3...-9 % on the 3-slot 3x3 shapes, +4 % on the 2-slot 256x192 tile
       STAMP(t2);
       compute_issue(c_slot, d_issued < total_steps);
+    } else if constexpr (SPLIT) {
+      if (c + 1 < total_steps) issue_w();          // W(c + 1) first, then X(c + 2): see the wait above
+      if (d_issued < total_steps) issue_x();
+      STAMP(t2);
+      compute(c_slot, cw_slot);
+      cw_slot ^= 1;
     } else {
       if (d_issued < total_steps) issue_next();
       STAMP(t2);
@@ -514,7 +598,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #if MIYOLO_ABLATE
     acc_wait += t1 - t0; acc_issue += t2 - t1; acc_comp += t3 - t2;
 #endif
-    c_slot = (c_slot == NST - 1) ? 0 : c_slot + 1;
+    c_slot = (c_slot == (SPLIT ? NXS : NST) - 1) ? 0 : c_slot + 1;
     if (++c_ks == a.nk) {
       // ---- epilogue of tile c_tile (the next tile's first stages are already in flight)
       const int mb = c_tile / NB, nb = c_tile - mb * NB;
