@@ -320,6 +320,10 @@ def classify_block(dev, local, steps=200):
 def kernel_name(cfg, kind, dtype):
     if not cfg:
         return {0: "stem", 2: "maxpool5", 3: "decode", 4: "cls_head"}.get(kind, "op")
+    if cfg >= 10000:
+        return "conv_pw<%s,nt%d>" % (dtype, cfg % 100)             # streaming 1x1 kernel (option pw, off by default)
+    if cfg >= 9400:
+        return "conv_stem2<%s,tc%d>" % (dtype, cfg % 10)           # the stem and the stride-2 conv behind it in one launch
     if cfg >= 9000:
         return "conv_bneck<%s,tc%d>" % (dtype, cfg % 10)           # two 3x3 convs of a narrow Bottleneck in one launch
     fam = ("conv_h3" if cfg >= 8000 and (cfg // 10) % 10 == 5 else "conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else
@@ -377,6 +381,12 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
             fl += f2
             if cfg < 9000:
                 by += b2
+            elif 9400 <= cfg < 9500:
+                # stem + layer 1 in one launch: the stem's map (its output, layer 1's input) never touches HBM
+                o2 = eng.prog.ops[nxt]
+                es = {"f16": 2, "f32": 4, "f8": 1}[dtype]
+                stem_map = min(chunk, B) * (H // o.down_out) * (W // o.down_out) * o.cout * es
+                by += b2 - 2 * stem_map
             nxt += 1
         e0 = perop.setdefault(op, {"name": o.name, "kind": o.kind, "k": o.ksize, "s": o.stride, "cin": o.cin, "cout": o.cout,
                                    "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl, "bytes": by})
