@@ -381,12 +381,13 @@ def roofline_block(eng, step, steps, B, H, W, dtype, dev, profile_out=""):
             fl += f2
             if cfg < 9000:
                 by += b2
-            elif 9400 <= cfg < 9500:
-                # stem + layer 1 in one launch: the stem's map (its output, layer 1's input) never touches HBM
-                o2 = eng.prog.ops[nxt]
+            elif 9400 <= cfg < 9600:
+                # stem + layer 1 (+ the 1x1 conv behind it, 95xx) in one launch: the map between two of its ops (one's output,
+                # the next one's input) never touches HBM
+                prev = eng.prog.ops[nxt - 1]
                 es = {"f16": 2, "f32": 4, "f8": 1}[dtype]
-                stem_map = min(chunk, B) * (H // o.down_out) * (W // o.down_out) * o.cout * es
-                by += b2 - 2 * stem_map
+                inner_map = min(chunk, B) * (H // prev.down_out) * (W // prev.down_out) * prev.cout * es
+                by += b2 - 2 * inner_map
             nxt += 1
         e0 = perop.setdefault(op, {"name": o.name, "kind": o.kind, "k": o.ksize, "s": o.stride, "cin": o.cin, "cout": o.cout,
                                    "down": o.down_out, "cfg": cfg, "n": 0, "ms": 0.0, "flop": fl, "bytes": by})

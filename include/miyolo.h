@@ -219,7 +219,8 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * default: three chained MAXPOOL5 ops run as one launch; same results), "bneck_fuse" (1 default: in F16 a narrow Bottleneck -
  * conv3x3, conv3x3 + residual of the first one's input, 16 / 32 / 48 channels, the intermediate read by nobody else - runs
  * as one launch with the intermediate tile in LDS; same results as the two launches on the 2-D-tile kernel), "stem_fuse" (1
- * default: in F16 the stem and the stride-2 conv behind it run as one launch, the stem's map never written - same results), "batch_split" (0 default;
+ * default: in F16 the stem, the stride-2 conv behind it and - where it is a C1 -> C1 1x1 conv read by nobody else - the conv behind
+ * that run as one launch, the maps between them never written; 2: the first two only; 0: one launch each - same results), "batch_split" (0 default;
  * K > 1: a batch that fits one pass runs as K part batches on K streams when the workspace holds K part plans - measured
  * +0.8..1.4 % on configuration 1, left off), "cls_streams" (1 default:
  * > 1 makes miyolo_classify fork the batch over that many internal streams, joined by events - measured slower), and the

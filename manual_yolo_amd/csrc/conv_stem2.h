@@ -27,6 +27,8 @@ struct Stem2Args {
   const uint8_t* in;                        // [B][H][W][3]
   const void* w0; const float* b0;          // stem: [C0][32] f16 in the K' order of stem_kernel, bias
   const void* w1; const float* b1;          // layer 1: [C1][kpad] f16, bias
+  const void* w2; const float* b2;          // HAS3: the 1x1 conv behind layer 1 (C1 -> C1, a C2f's cv1): [C1][kpad2] f16, bias
+  int32_t kpad2, act2;
   void* dst; uint32_t dst_bytes, in_bytes;
   int32_t dst_ld, dst_choff, kpad;
   int32_t B, H, W, act0, act1;
@@ -37,17 +39,26 @@ struct Stem2Args {
 constexpr int kS2Oh = 8, kS2Ow = 8;                         // output tile of layer 1 (per wave group)
 constexpr int kS2Sh = 2 * kS2Oh + 1, kS2Sw = 2 * kS2Ow + 1;  // the stem pixels it reads: 17 x 17
 
-template <int TCS, int TC1> struct Stem2Geo {
-  static constexpr int C0 = TCS * 16, C1 = TC1 * 16, SROW = C0 * 2, CPT = C0 / 8, NCH = 9 * CPT, NG = (NCH + 3) / 4, WROW = NG * 64 + 32;   // pitch = 2 (mod 4) chunks: conflict-free weight fragments (conv_bneck.h)
+template <int TCS, int TC1, bool HAS3> struct Stem2Geo {
+  static constexpr int C0 = TCS * 16, C1 = TC1 * 16, SROW = C0 * 2, CPT = C0 / 8, NCH = 9 * CPT, NG = (NCH + 3) / 4;
+  // weight-row pitch: the smallest number of 16-byte chunks >= NCH that is 2 (mod 4) - conflict-free fragments (conv_bneck.h).
+  // For C0 = 48 that is NCH itself (54): the last K group's chunks 54, 55 then belong to the NEXT row (finite weights; 32 zero
+  // bytes behind the last row) and the pixel fragment is zeroed for them - 0 x finite adds nothing.
+  static constexpr int WCH = (NCH % 4 == 2) ? NCH : (NCH + 3) / 4 * 4 + 2, WROW = WCH * 16;
   static constexpr int NSPX = kS2Sh * kS2Sw, NST = (NSPX + 15) / 16, TPW = (NST + 3) / 4;     // stem pixels, their 16-pixel tiles, tiles per wave of a group
-  static constexpr int W_BYTES = C1 * WROW, KOFF_BYTES = NG * 16;
-  static constexpr int S_OFF = W_BYTES + KOFF_BYTES, S_BYTES = (NSPX * SROW + 255) / 256 * 256;   // one patch per group
-  static constexpr int LDS = S_OFF + 2 * S_BYTES;
+  static constexpr int W_BYTES = C1 * WROW + 32, KOFF_BYTES = NG * 16;
+  static constexpr int S_OFF = W_BYTES + KOFF_BYTES, S_BYTES = (NSPX * SROW + 63) / 64 * 64;   // one patch per group
+  // HAS3: the 1x1 conv's weights, [C1 rows][C1 channels], pitch 2 (mod 4) chunks
+  static constexpr int C2CH = C1 / 8, W2CH = (C2CH % 4 == 2) ? C2CH : C2CH + 2, W2ROW = W2CH * 16;
+  static constexpr int W2_OFF = S_OFF + 2 * S_BYTES, W2_BYTES = HAS3 ? C1 * W2ROW : 0;
+  static constexpr int LDS = W2_OFF + W2_BYTES;
+  static_assert(TC1 % 2 == 0, "layer 1's channel tiles are dealt in pairs");
 };
 
-template <int TCS, int TC1>
+template <int TCS, int TC1, bool HAS3>
 __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
-  typedef Stem2Geo<TCS, TC1> G;
+  typedef Stem2Geo<TCS, TC1, HAS3> G;
+  constexpr int NPAIR = TC1 / 2;
   constexpr int SROW = G::SROW, CPT = G::CPT, NG = G::NG, WROW = G::WROW, TPW = G::TPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -70,11 +81,24 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
     const int cpr = NG * 4;
     const size_t row_bytes = (size_t)a.kpad * 2;
     const unsigned char* wgp = reinterpret_cast<const unsigned char*>(a.w1);
-    for (int e = tid; e < G::C1 * cpr; e += 512) {
-      const int n = e / cpr, c = e - n * cpr;
+    // LDS row r holds output channel pi(r) (the pair deal of conv_h2.h: tile 2p row 4q+j -> channel 32p + 8q + j, tile 2p+1 -> + 4):
+    // a lane ends up with 8 CONSECUTIVE channels of its pixel over a tile pair - one 16-byte store per pair, and, for HAS3,
+    // exactly the MFMA B fragment of the 1x1 conv's K slice p: layer 1's activations feed it without leaving the registers.
+    auto pi = [](int r) { const int ti = r >> 4, rho = r & 15; return 32 * (ti >> 1) + 8 * (rho >> 2) + 4 * (ti & 1) + (rho & 3); };
+    for (int e = tid; e < G::C1 * G::WCH; e += 512) {
+      const int n = e / G::WCH, c = e - n * G::WCH;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if ((size_t)(c + 1) * 16 <= row_bytes) v = *reinterpret_cast<const uint4*>(wgp + (size_t)n * row_bytes + c * 16);
+      if (c < cpr && (size_t)(c + 1) * 16 <= row_bytes) v = *reinterpret_cast<const uint4*>(wgp + (size_t)pi(n) * row_bytes + c * 16);
       *reinterpret_cast<uint4*>(wl + n * WROW + c * 16) = v;
+    }
+    if (tid < 2) *reinterpret_cast<uint4*>(wl + G::C1 * WROW + tid * 16) = make_uint4(0, 0, 0, 0);
+    if constexpr (HAS3) {
+      const unsigned char* w2p = reinterpret_cast<const unsigned char*>(a.w2);
+      const size_t row2 = (size_t)a.kpad2 * 2;
+      for (int e = tid; e < G::C1 * G::C2CH; e += 512) {
+        const int n = e / G::C2CH, c = e - n * G::C2CH;
+        *reinterpret_cast<uint4*>(smem + G::W2_OFF + n * G::W2ROW + c * 16) = *reinterpret_cast<const uint4*>(w2p + (size_t)pi(n) * row2 + c * 16);
+      }
     }
     for (int q = tid; q < NG * 4; q += 512) {
       int v = 0;
@@ -98,7 +122,14 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
 #pragma unroll
   for (int i = 0; i < TC1; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b1v[i][r] = a.b1[i * 16 + fq * 4 + r];
+    for (int r = 0; r < 4; ++r) b1v[i][r] = a.b1[32 * (i >> 1) + 8 * fq + 4 * (i & 1) + r];      // this lane's channels under pi
+  float b2v[HAS3 ? TC1 : 1][4];
+  if constexpr (HAS3) {
+#pragma unroll
+    for (int i = 0; i < TC1; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b2v[i][r] = a.b2[32 * (i >> 1) + 8 * fq + 4 * (i & 1) + r];
+  }
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.in), 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst_bytes, 0x00020000);
@@ -194,7 +225,8 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
     for (int i = 0; i < TC1; ++i) afn[i] = *reinterpret_cast<const uint4*>(wl + abase[i]);
 #pragma unroll
     for (int kg = 0; kg < NG; ++kg) {
-      const uint4 bf = bfn;
+      uint4 bf = bfn;
+      if (kg == NG - 1 && (G::NCH & 3) && fq >= (G::NCH & 3)) bf = make_uint4(0, 0, 0, 0);     // chunks beyond the row (see Stem2Geo)
       uint4 af[TC1];
 #pragma unroll
       for (int i = 0; i < TC1; ++i) af[i] = afn[i];
@@ -209,18 +241,51 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     const int m = (b * Ho + ty * kS2Oh + oy_l) * Wo + tx * kS2Ow + ox_l;
+    // layer 1's activations: per channel-tile pair 8 consecutive channels of this lane's pixel, f16
+    uint4 y1[NPAIR];
 #pragma unroll
-    for (int i = 0; i < TC1; ++i) {
-      const int n = i * 16 + fq * 4;
-      float v[4];
+    for (int p = 0; p < NPAIR; ++p) {
+      float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc1[i][r] + b1v[i][r];
-        if (a.act1) x = silu_fast(x);
-        v[r] = x;
+        float x0 = acc1[2 * p][r] + b1v[2 * p][r], x1 = acc1[2 * p + 1][r] + b1v[2 * p + 1][r];
+        if (a.act1) { x0 = silu_fast(x0); x1 = silu_fast(x1); }
+        v[r] = x0; v[4 + r] = x1;
       }
-      const f16x4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2i_t*>(&hv), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2), 0, 0);
+      const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+      y1[p] = *reinterpret_cast<const uint4*>(&hv);
+    }
+    if constexpr (!HAS3) {
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p)
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&y1[p]), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + 32 * p + 8 * fq) * 2), 0, 0);
+    } else {
+      // the 1x1 conv behind layer 1 (a C2f's cv1, C1 -> C1): y1[p] IS the B fragment of its K slice p (channels 32 p + 8 fq .. + 7
+      // of pixel frow); K slices in ascending order, as the ring kernel runs them.  Layer 1's map never touches HBM either.
+      const unsigned char* w2l = smem + G::W2_OFF;
+      f32x4 acc2[TC1];
+#pragma unroll
+      for (int i = 0; i < TC1; ++i) acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        uint4 af2[TC1];
+#pragma unroll
+        for (int i = 0; i < TC1; ++i) af2[i] = *reinterpret_cast<const uint4*>(w2l + (i * 16 + frow) * G::W2ROW + (p * 4 + fq) * 16);
+#pragma unroll
+        for (int i = 0; i < TC1; ++i) Mma<half_t>::run(af2[i], y1[p], acc2[i]);
+      }
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x0 = acc2[2 * p][r] + b2v[2 * p][r], x1 = acc2[2 * p + 1][r] + b2v[2 * p + 1][r];
+          if (a.act2) { x0 = silu_fast(x0); x1 = silu_fast(x1); }
+          v[r] = x0; v[4 + r] = x1;
+        }
+        const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, (uint32_t)((m * a.dst_ld + a.dst_choff + 32 * p + 8 * fq) * 2), 0, 0);
+      }
     }
   };
 
@@ -245,33 +310,36 @@ __global__ __launch_bounds__(512) void conv_stem2_kernel(const Stem2Args a) {
 }
 
 // host side ------------------------------------------------------------------------------------------------------
-inline bool stem2_shape_ok(int C0, int C1, int H, int W, size_t* lds) {
+inline bool stem2_shape_ok(int C0, int C1, int H, int W, bool has3, size_t* lds) {
   if (H % (4 * kS2Oh) || W % (4 * kS2Ow)) return false;           // whole 8 x 8 tiles of layer 1's map
-  if (C0 == 48 && C1 == 96) *lds = Stem2Geo<3, 6>::LDS;
-  else if (C0 == 16 && C1 == 32) *lds = Stem2Geo<1, 2>::LDS;
-  else if (C0 == 32 && C1 == 64) *lds = Stem2Geo<2, 4>::LDS;
+  if (C0 == 48 && C1 == 96) *lds = has3 ? Stem2Geo<3, 6, true>::LDS : Stem2Geo<3, 6, false>::LDS;
+  else if (C0 == 16 && C1 == 32) *lds = has3 ? Stem2Geo<1, 2, true>::LDS : Stem2Geo<1, 2, false>::LDS;
+  else if (C0 == 32 && C1 == 64) *lds = has3 ? Stem2Geo<2, 4, true>::LDS : Stem2Geo<2, 4, false>::LDS;
   else return false;
   return *lds <= 160 * 1024;
 }
 
-inline hipError_t launch_conv_stem2(Stem2Args a, int C0, int C1, hipStream_t s, int ncu) {
+inline hipError_t launch_conv_stem2(Stem2Args a, int C0, int C1, bool has3, hipStream_t s, int ncu) {
   size_t lds;
-  if (!stem2_shape_ok(C0, C1, a.H, a.W, &lds)) return hipErrorInvalidValue;
+  if (!stem2_shape_ok(C0, C1, a.H, a.W, has3, &lds)) return hipErrorInvalidValue;
   a.tiles_x = a.W / 4 / kS2Ow; a.tiles_y = a.H / 4 / kS2Oh; a.ntiles = a.B * a.tiles_x * a.tiles_y;
   host_magic((uint32_t)(a.tiles_x * a.tiles_y), &a.mg_img_mul, &a.mg_img_shift);
   host_magic((uint32_t)a.tiles_x, &a.mg_tx_mul, &a.mg_tx_shift);
   long grid = std::min<long>(a.ntiles, ncu);
   grid = (grid + 7) / 8 * 8;
-  if (C0 == 48) hipLaunchKernelGGL((conv_stem2_kernel<3, 6>), dim3((unsigned)grid), dim3(512), lds, s, a);
-  else if (C0 == 16) hipLaunchKernelGGL((conv_stem2_kernel<1, 2>), dim3((unsigned)grid), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((conv_stem2_kernel<2, 4>), dim3((unsigned)grid), dim3(512), lds, s, a);
+  const dim3 g((unsigned)grid), b(512);
+  if (C0 == 48) { if (has3) hipLaunchKernelGGL((conv_stem2_kernel<3, 6, true>), g, b, lds, s, a); else hipLaunchKernelGGL((conv_stem2_kernel<3, 6, false>), g, b, lds, s, a); }
+  else if (C0 == 16) { if (has3) hipLaunchKernelGGL((conv_stem2_kernel<1, 2, true>), g, b, lds, s, a); else hipLaunchKernelGGL((conv_stem2_kernel<1, 2, false>), g, b, lds, s, a); }
+  else { if (has3) hipLaunchKernelGGL((conv_stem2_kernel<2, 4, true>), g, b, lds, s, a); else hipLaunchKernelGGL((conv_stem2_kernel<2, 4, false>), g, b, lds, s, a); }
   return hipGetLastError();
 }
 
 inline hipError_t set_stem2_attrs() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem2_kernel<3, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem2_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipSuccess;
+  auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+  set(reinterpret_cast<const void*>(conv_stem2_kernel<3, 6, true>)); set(reinterpret_cast<const void*>(conv_stem2_kernel<3, 6, false>));
+  set(reinterpret_cast<const void*>(conv_stem2_kernel<1, 2, true>)); set(reinterpret_cast<const void*>(conv_stem2_kernel<1, 2, false>));
+  set(reinterpret_cast<const void*>(conv_stem2_kernel<2, 4, true>)); set(reinterpret_cast<const void*>(conv_stem2_kernel<2, 4, false>));
   return e;
 }
 

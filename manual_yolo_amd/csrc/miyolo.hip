@@ -686,36 +686,59 @@ bool try_sppf3(miyolo_engine* h, int i, int last, const Plan& p, const void* in,
 }
 
 // ops i (the stem) and i+1 (conv3x3 stride 2 on the stem's output, which nobody else reads)?  Then one launch (conv_stem2.h).
-bool try_stem2(miyolo_engine* h, int i, int last, const Plan& p, const void* in, void* ws, hipStream_t s) {
-  if (!h->stem_fuse || h->desc.dtype != MIYOLO_F16 || i + 1 >= last) return false;
+// If op i+2 is a 1x1 conv C1 -> C1 on layer 1's whole output (a C2f's cv1) and nobody else reads that output, it joins the
+// launch (layer 1's activations are its MFMA operand as they stand): returns the number of ops absorbed (0: no fusion).
+int try_stem2(miyolo_engine* h, int i, int last, const Plan& p, const void* in, void* ws, hipStream_t s, bool allow3) {
+  if (!h->stem_fuse || h->desc.dtype != MIYOLO_F16 || i + 1 >= last) return 0;
   const miyolo_op& o0 = h->ops[i];
   const miyolo_op& o1 = h->ops[i + 1];
-  if (o0.kind != MIYOLO_OP_STEM || o1.kind != MIYOLO_OP_CONV || o1.ksize != 3 || o1.stride != 2 || o1.n_src != 1 || o1.src[0].upsample || o1.res.buf >= 0) return false;
+  if (o0.kind != MIYOLO_OP_STEM || o1.kind != MIYOLO_OP_CONV || o1.ksize != 3 || o1.stride != 2 || o1.n_src != 1 || o1.src[0].upsample || o1.res.buf >= 0) return 0;
   const miyolo_buf& sb = h->bufs[o0.dst.buf];
-  const miyolo_buf& yb = h->bufs[o1.dst.buf];
-  if (sb.dtype != -1 || yb.dtype != -1 || sb.down != 2 || yb.down != 4 || sb.channels != o0.cout || o0.dst.ch_off != 0) return false;
-  if (o1.src[0].buf != o0.dst.buf || o1.src[0].ch_off != 0 || o1.src[0].ch_cnt != o0.cout || o1.cin != o0.cout) return false;
-  for (int k = 0; k < (int)h->ops.size(); ++k) {            // the stem's map is read by layer 1 only
-    if (k == i + 1) continue;
-    const miyolo_op& o = h->ops[k];
-    const int ns = o.kind == MIYOLO_OP_CONV ? o.n_src : o.kind == MIYOLO_OP_DECODE ? 3 : 1;
-    if (o.kind != MIYOLO_OP_STEM) for (int q = 0; q < ns; ++q) if (o.src[q].buf == o0.dst.buf) return false;
-    if (o.kind == MIYOLO_OP_CONV && o.res.buf == o0.dst.buf) return false;
+  const miyolo_buf& yb1 = h->bufs[o1.dst.buf];
+  if (sb.dtype != -1 || yb1.dtype != -1 || sb.down != 2 || yb1.down != 4 || sb.channels != o0.cout || o0.dst.ch_off != 0) return 0;
+  if (o1.src[0].buf != o0.dst.buf || o1.src[0].ch_off != 0 || o1.src[0].ch_cnt != o0.cout || o1.cin != o0.cout) return 0;
+  auto read_only_by = [&](int buf, int reader) {              // is `buf` read by op `reader` only?
+    for (int k = 0; k < (int)h->ops.size(); ++k) {
+      if (k == reader) continue;
+      const miyolo_op& o = h->ops[k];
+      const int ns = o.kind == MIYOLO_OP_CONV ? o.n_src : o.kind == MIYOLO_OP_DECODE ? 3 : 1;
+      if (o.kind != MIYOLO_OP_STEM) for (int q = 0; q < ns; ++q) if (o.src[q].buf == buf) return false;
+      if (o.kind == MIYOLO_OP_CONV && o.res.buf == buf) return false;
+    }
+    return true;
+  };
+  if (!read_only_by(o0.dst.buf, i + 1)) return 0;
+  bool has3 = false;
+  if (allow3 && h->stem_fuse >= 1 && h->stem_fuse != 2 && i + 2 < last) {        // option stem_fuse = 2: two ops only
+    const miyolo_op& o2 = h->ops[i + 2];
+    const miyolo_buf& y2 = h->bufs[o2.dst.buf];
+    has3 = o2.kind == MIYOLO_OP_CONV && o2.ksize == 1 && o2.stride == 1 && o2.n_src == 1 && !o2.src[0].upsample && o2.res.buf < 0 &&
+           o2.src[0].buf == o1.dst.buf && o2.src[0].ch_off == 0 && o2.src[0].ch_cnt == o1.cout && o2.cin == o1.cout && o2.cout == o1.cout &&
+           o1.dst.ch_off == 0 && yb1.channels == o1.cout && o1.cout % 32 == 0 &&
+           y2.dtype == -1 && y2.down == 4 && y2.channels % 8 == 0 && o2.dst.ch_off % 8 == 0 && read_only_by(o1.dst.buf, i + 2);
   }
+  const miyolo_op& od = has3 ? h->ops[i + 2] : o1;
+  const miyolo_buf& yb = h->bufs[od.dst.buf];
   size_t lds;
-  if (!stem2_shape_ok(o0.cout, o1.cout, p.H, p.W, &lds)) return false;
-  if (yb.channels % 4 || o1.dst.ch_off % 4) return false;
+  if (!stem2_shape_ok(o0.cout, o1.cout, p.H, p.W, has3, &lds)) return 0;
+  if (yb.channels % 8 || od.dst.ch_off % 8) return 0;           // 16-byte stores
   const size_t inb = (size_t)p.B * p.H * p.W * 3, yb_bytes = (size_t)p.B * (p.H / 4) * (p.W / 4) * yb.channels * 2;
-  if (inb >= ((size_t)1 << 31) || yb_bytes >= ((size_t)1 << 31)) return false;
+  if (inb >= ((size_t)1 << 31) || yb_bytes >= ((size_t)1 << 31)) return 0;
   Stem2Args a;
   memset(&a, 0, sizeof(a));
   a.in = static_cast<const uint8_t*>(in); a.in_bytes = (uint32_t)inb;
   a.w0 = h->weights[o0.weight]; a.b0 = static_cast<const float*>(h->weights[o0.bias]);
   a.w1 = h->weights[o1.weight]; a.b1 = static_cast<const float*>(h->weights[o1.bias]);
-  a.dst = buf_ptr(h, p, o1.dst.buf, in, ws); a.dst_bytes = (uint32_t)yb_bytes; a.dst_ld = yb.channels; a.dst_choff = o1.dst.ch_off;
+  if (has3) {
+    const miyolo_op& o2 = h->ops[i + 2];
+    a.w2 = h->weights[o2.weight]; a.b2 = static_cast<const float*>(h->weights[o2.bias]);
+    a.kpad2 = (o2.cin + 63) / 64 * 64; a.act2 = o2.act;
+  }
+  a.dst = buf_ptr(h, p, od.dst.buf, in, ws); a.dst_bytes = (uint32_t)yb_bytes; a.dst_ld = yb.channels; a.dst_choff = od.dst.ch_off;
   a.kpad = (9 * o0.cout + 63) / 64 * 64;
   a.B = p.B; a.H = p.H; a.W = p.W; a.act0 = o0.act; a.act1 = o1.act;
-  return launch_conv_stem2(a, o0.cout, o1.cout, s, h->ncu) == hipSuccess;
+  if (launch_conv_stem2(a, o0.cout, o1.cout, has3, s, h->ncu) != hipSuccess) return 0;
+  return has3 ? 2 : 1;
 }
 
 // ops i, i+1 = a narrow Bottleneck (conv3x3 -> conv3x3 + residual of the first one's input, C -> C -> C channels, the
@@ -793,10 +816,12 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
       HIP_TRY(h, hipEventRecord(rec.e0, s));
     }
     int fusedn = 0;
+    bool stem_fused = false;
     if (h->ops[i].kind == MIYOLO_OP_STEM && i + 1 < last && (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) &&
-        try_stem2(h, i, last, p, in, ws, si)) {
-      fusedn = 1;
-      rec.cfg = 9000 + 400 + h->ops[i + 1].cout / 16;        // conv_stem2_kernel
+        (fusedn = try_stem2(h, i, last, p, in, ws, si,
+                            i + 2 < last && (!lanes || (h->op_lane[i] == h->op_lane[i + 2] && h->op_waits[i + 2].empty())))) > 0) {
+      rec.cfg = 9000 + (fusedn == 2 ? 500 : 400) + h->ops[i + 1].cout / 16;        // conv_stem2_kernel (95xx: + the 1x1 conv behind layer 1)
+      stem_fused = true;
     } else if (h->ops[i].kind == MIYOLO_OP_CONV && h->ops[i].ksize == 3 && i + 1 < last &&
         (!lanes || (h->op_lane[i] == h->op_lane[i + 1] && h->op_waits[i + 1].empty())) && try_bneck(h, i, last, p, in, ws, si)) {
       fusedn = 1;
@@ -814,9 +839,12 @@ int run_ops(miyolo_engine* h, int first, int last, const Plan& p, const void* in
     ++h->launches;                                         // every op (fused or not) is exactly one kernel launch
     if (h->ops[i].kind == MIYOLO_OP_STEM || h->ops[i].kind == MIYOLO_OP_CONV) {
       // the stem+conv and Bottleneck fusions (one absorbed op) keep the FIRST op's output in LDS: that buffer is never written
-      const bool kept_in_lds = fusedn == 1;
+      const bool kept_in_lds = fusedn == 1 || stem_fused;
       h->buf_stale[h->ops[i].dst.buf] = kept_in_lds;
-      if (kept_in_lds) h->buf_stale[h->ops[i + 1].dst.buf] = 0;
+      if (kept_in_lds) {
+        for (int k = 1; k < fusedn; ++k) h->buf_stale[h->ops[i + k].dst.buf] = 1;      // stem + layer 1 + 1x1: layer 1's map too
+        h->buf_stale[h->ops[i + fusedn].dst.buf] = 0;
+      }
     }
     for (int k = 0; k < fusedn; ++k, ++i)                  // the two absorbed pools: same lane, their events mean the same launch
       if (lanes && h->op_signal[i]) HIP_TRY(h, hipEventRecord(h->op_ev[i], si));

@@ -22,6 +22,6 @@ for o in ops:
     lines.append(f"| {o['name']} | {kinds.get(o['kind'], o['kind'])} | {o['k']} | {o['cin']}->{o['cout']} | {o['down']} | {o['cfg']} | "
                  f"{ms * 1e3:.1f} | {o['tflops']:.0f} | {o['gbs']:.0f} | {'mfma' if tf >= tb else 'hbm'} | {tmin * 1e3 / ms:.3f} |")
 lines += ["", f"Sum of kernel times {tot_ms:.3f} ms per step; sum of per-layer t_min {tot_min:.3f} ms; layer-wise mixed roofline fraction "
-          f"{tot_min / tot_ms:.3f}.  cfg = impl*1000 + ksize*100 + WC*10 + TC (3 = conv_dmap, 7 = conv_t2d, 8 = conv_h2 with WC = 4 waves, 9 = conv_bneck: a fused Bottleneck, its row carries both convs' flops; 94xx = conv_stem2: the stem and model.1 in one launch, the row carries both layers' flops and the frame + model.1's output as bytes)."]
+          f"{tot_min / tot_ms:.3f}.  cfg = impl*1000 + ksize*100 + WC*10 + TC (3 = conv_dmap, 7 = conv_t2d, 8 = conv_h2 with WC = 4 waves, 9 = conv_bneck: a fused Bottleneck, its row carries both convs' flops; 94xx / 95xx = conv_stem2: the stem and model.1 (95xx: and model.2.cv1) in one launch, the row carries all their flops and the frame + the last layer's output as bytes)."]
 open(out, "w").write("\n".join(lines) + "\n")
 print(lines[-1])
