@@ -171,6 +171,8 @@ __global__ __launch_bounds__(512) void conv_bneck_kernel(const BneckArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const bool three = wave + 16 < 21;                         // wave-uniform: waves 5..7 have two pixel tiles
+      // (Round 3 tried reading K group kg + 1's fragments before kg's MFMAs here and in conv B, as conv_stem2.h does: 247 vs 240 us on a
+      // box that ran everything 3 % slower - nothing.  The partner wave on the SIMD already covers these latencies.)
 #pragma unroll 2
       for (int kg = 0; kg < NG; ++kg) {
         const int ko = koffA[kg * 4 + fq];
