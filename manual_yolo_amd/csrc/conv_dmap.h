@@ -52,8 +52,10 @@
 
 // The 256 x 192 tile (2-slot ring): activations and weights in SEPARATE rings - three activation slots (two K steps ahead),
 // two weight slots (one ahead): 144 KiB instead of 112.  See the kernel.
+// 2 (default): as 1, with the step's DMAs spread between its MFMAs (as MIYOLO_DMAP_INTERLEAVE does for the 3-slot shapes):
+// -6 % / -9.5 % on the two stride-2 3x3 layers of this shape (model.3, model.16) against the burst form, the 1x1 layers even.
 #ifndef MIYOLO_DMAP_SPLIT
-#define MIYOLO_DMAP_SPLIT 1
+#define MIYOLO_DMAP_SPLIT 2
 #endif
 
 namespace miyolo {
@@ -480,6 +482,59 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     }
   };
 
+  // SPLIT with the step's DMAs spread between its MFMAs (MIYOLO_DMAP_SPLIT == 2): the weight DMAs of W(c + 1) first, then the
+  // activation DMAs of X(c + 2) - the issue order the wait at the top of a step relies on.
+  auto compute_issue_split = [&](int slot, int wslot, const bool do_w, const bool do_x) {
+    const uint32_t stx = lds_base + (uint32_t)(d_slot * XSTAGE + wave * 1024);
+    const uint32_t stw = lds_base + (uint32_t)(NXS * XSTAGE + w_slot * WSTAGE + wave * 1024);
+    const int ks = d_ks;
+    const uint32_t e = ktab[ks * 8 + cg];
+    const uint32_t tp = e >> 28;
+    const uint32_t kofs = (KS == 3) ? (e & 0x0FFFFFFFu) : (e & 0x8FFFFFFFu);
+    const bool seg1 = (KS == 1) && (ks * 8) >= ct0;
+    const uint32_t wk = (uint32_t)(w_ks * 128);
+    auto issue_one = [&](int d) {                    // d < NI - XI: weight DMA d; else activation DMA d - (NI - XI)
+      if (d < NI - XI) {
+        if (do_w) lds_dma16(rsw, stw + d * 8192, woff[d] + wk);
+      } else if (do_x) {
+        const int i = d - (NI - XI);
+        if constexpr (KS == 3) lds_dma16(rs0, stx + i * 8192, ((uint32_t)xoff0[i] + kofs) | (((xinv[i] >> tp) & 1u) << 31));
+        else if (!seg1) lds_dma16(rs0, stx + i * 8192, ((uint32_t)xoff0[i] + kofs) | xinv[i]);
+        else lds_dma16(rs1, stx + i * 8192, ((uint32_t)xoff1[KS == 1 ? i : 0] + kofs) | xinv[i]);
+      }
+    };
+    constexpr int NM = 2 * TC * TPW;
+    const unsigned char* xs = smem + slot * XSTAGE;
+    const unsigned char* ws = smem + NXS * XSTAGE + wslot * WSTAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[TC], bf[TPW];
+#pragma unroll
+      for (int i = 0; i < TC; ++i) af[i] = *reinterpret_cast<const uint4*>(ws + lds_off((wc * TC + i) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) bf[j] = *reinterpret_cast<const uint4*>(xs + lds_off((wp * TPW + j) * 16 + frow, kk * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          Mma<T>::run(af[i], bf[j], acc[i][j]);
+          const int q = (kk * TC + i) * TPW + j;     // constant after unrolling
+#pragma unroll
+          for (int d = 0; d < NI; ++d)
+            if (q == (d * NM) / NI) issue_one(d);
+        }
+    }
+    if (do_w) {
+      w_slot ^= 1;
+      if (++w_ks == a.nk) { w_ks = 0; w_tile += G; if (w_tile < ntiles) set_w(w_tile); }
+    }
+    if (do_x) {
+      d_slot = (d_slot == NXS - 1) ? 0 : d_slot + 1;
+      ++d_issued;
+      if (++d_ks == a.nk) { d_ks = 0; d_tile += G; if (d_tile < ntiles) setup_tile(d_tile); }
+    }
+  };
+
   // ---- deferred epilogue (MIYOLO_DMAP_DEFER, OFF: measured 8 % slower on the whole step, same box, back to back):
   // a finished tile's accumulators move to a second register set and its bias + SiLU + store run one 16x16 piece per K
   // step of the NEXT tile, right after that step's MFMAs have been issued.  The idea was that the matrix pipe works
@@ -580,6 +635,10 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
     if constexpr (MIYOLO_DMAP_INTERLEAVE && (NST > 2 || MIYOLO_DMAP_INTERLEAVE > 1)) {      // measured: -3...-9 % on the 3-slot 3x3 shapes, +4 % on the 2-slot 256x192 tile
       STAMP(t2);
       compute_issue(c_slot, d_issued < total_steps);
+    } else if constexpr (SPLIT && MIYOLO_DMAP_SPLIT == 2 && !is_fp8<T>::value) {
+      STAMP(t2);
+      compute_issue_split(c_slot, cw_slot, c + 1 < total_steps, d_issued < total_steps);
+      cw_slot ^= 1;
     } else if constexpr (SPLIT) {
       if (c + 1 < total_steps) issue_w();          // W(c + 1) first, then X(c + 2): see the wait above
       if (d_issued < total_steps) issue_x();

@@ -10,12 +10,12 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(conv_h3_kernel|conv_h2_kernel|conv_bneck_kernel|conv_stem2_kernel|cls_mega_kernel|sppf3_kernel|greedy_nmm_kernel|zero_i32_kernel|conv_t2d_kernel|conv_halop_kernel|conv_halo_kernel|conv_dmap_kernel|conv_dmh_kernel|conv_ws_kernel|conv_dma_kernel|conv_igemm_kernel|stem_kernel|maxpool5_kernel|decode_kernel|"
+    m = re.search(r"(conv_h3_kernel|conv_h2_kernel|conv_bneck_kernel|conv_stem2_kernel|conv_pw_kernel|cls_mega_kernel|sppf3_kernel|greedy_nmm_kernel|zero_i32_kernel|conv_t2d_kernel|conv_halop_kernel|conv_halo_kernel|conv_dmap_kernel|conv_dmh_kernel|conv_ws_kernel|conv_dma_kernel|conv_igemm_kernel|stem_kernel|maxpool5_kernel|decode_kernel|"
                   r"nms_sort_greedy_kernel|nms_prefilter_kernel|cls_head_kernel)", name)
     if not m:
         return name[:40]
     k = m.group(1)
-    if k in ("conv_h3_kernel", "conv_bneck_kernel"):
+    if k in ("conv_h3_kernel", "conv_bneck_kernel", "conv_stem2_kernel"):
         nums = re.findall(r"Li(\d+)E", name) or re.findall(r"[<,] ?(\d+)(?=[,>])", name)
         return f"{k.replace('_kernel', '')}<f16,{','.join(nums)}>"
     d = re.search(r"<(_Float16|float|miyolo::fp8_t)((?:, \w+)*)>", name)          # demangled form (rocprofv3 prints either)
