@@ -879,13 +879,16 @@ inline double dmap_cost(int cout, long M, int ncu, ConvCfg c) {
   if (c.wc == 1) cost *= 1.05;
   return cost;
 }
-inline ConvCfg pick_dmap_cfg(int cout, long M, int ncu) {
+inline ConvCfg pick_dmap_cfg(int cout, long M, int ncu, int ksize = 1) {
   static const ConvCfg cands[] = {{2, 6}, {2, 4}, {2, 3}, {1, 4}, {1, 3}, {1, 2}, {1, 1}};
   const long mbk = (M + DMA_BM - 1) / DMA_BM;
   ConvCfg best = {1, 1};
   double best_cost = 1e30;
   for (const ConvCfg& c : cands) {
-    if (c.tc == 6 && (mbk * ((cout + 191) / 192) < ncu || cout % 192)) continue;
+    // the 256 x 192 tile wanted at least one tile per CU on its 2-slot ring; with the split rings a 3x3 layer whose tiles fill
+    // most of ONE round beats two rounds of smaller tiles (model.19, 384 -> 384 stride 2 at 20 x 20: 200 tiles, 103 -> 85 us);
+    // the 1x1 layers of that size keep the rule (measured slower)
+    if (c.tc == 6 && (cout % 192 || (mbk * ((cout + 191) / 192) < ncu && !(ksize == 3 && mbk * ((cout + 191) / 192) * 4 >= ncu * 3)))) continue;
     const double cost = dmap_cost(cout, M, ncu, c);
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
@@ -894,7 +897,7 @@ inline ConvCfg pick_dmap_cfg(int cout, long M, int ncu) {
 
 template <typename T>
 inline hipError_t launch_conv_dmap(const ConvArgs& a, hipStream_t s, int ncu, int force_wc = 0, int force_tc = 0, int pair8 = 1) {
-  ConvCfg c = pick_dmap_cfg(a.cout, a.M, ncu);
+  ConvCfg c = pick_dmap_cfg(a.cout, a.M, ncu, a.ksize);
   if (force_wc > 0 && force_tc > 0) c = {force_wc, force_tc};
   ConvArgs b = a;
   b.pair8 = (pair8 && sizeof(T) == 2 && !a.out_f32 && a.vec_ok && a.cout % 16 == 0 && a.dst_ld % 8 == 0 && a.dst_choff % 8 == 0 &&

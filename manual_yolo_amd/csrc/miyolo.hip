@@ -583,7 +583,7 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
   if (op.ksize == 1 && h->conv_impl == 3 && h->pw && h->force_wc == 0 && h->desc.dtype == MIYOLO_F16 && pw_op_eligible(h, op))
     return 10000 + 100 + pw_nt(op.cout);                    // conv_pw_kernel<NT,NB>: 10112 / 10106
   int impl = h->conv_impl >= 3 ? 3 : (h->conv_impl >= 1 ? 1 : 0);
-  ConvCfg c = impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
+  ConvCfg c = impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu, op.ksize) : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
 #if MIYOLO_EXPERIMENTS
   {
     const bool halo = h->conv_impl == 2 && op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample &&
@@ -594,7 +594,7 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
     const size_t dmh_lds = dmh_lds_bytes() + (size_t)((op.cin * op.ksize * op.ksize + bk - 1) / bk) * 32;
     const bool dmh_auto = h->conv_impl == 3 && h->dmh_auto && h->force_wc == 0 && dmh_preferred_shape(op.cout, M, h->ncu) && dmh_lds <= 80 * 1024;
     impl = (h->conv_impl == 6 || dmh_auto) ? 6 : h->conv_impl == 5 ? 5 : halop ? 4 : h->conv_impl >= 3 ? 3 : halo ? 2 : (h->conv_impl >= 1 ? 1 : 0);
-    c = impl == 6 ? pick_dma_cfg(op.cout, M) : impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu) : impl == 2 ? pick_halo_cfg(op.cout, M)
+    c = impl == 6 ? pick_dma_cfg(op.cout, M) : impl == 5 ? pick_ws_cfg(op.cout, M) : impl == 4 ? pick_halop_cfg(op.cout, M) : impl == 3 ? pick_dmap_cfg(op.cout, M, h->ncu, op.ksize) : impl == 2 ? pick_halo_cfg(op.cout, M)
         : impl == 1 ? pick_dma_cfg(op.cout, M) : pick_conv_cfg(op.cout, M);
   }
 #endif
