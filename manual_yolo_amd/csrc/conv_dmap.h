@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
   // instead of two 8-byte ones: 16 rows x 64 B per store instruction instead of 16 x 32 B.  Same arithmetic per output:
   // results do not change.  In isolation the 32-byte pieces write at 4.4-5.5 TB/s, the 64-byte ones at 5.7-6.4
   // (tools/probes/probe_store_patterns.hip, profiles/r03_probe_store_patterns.log).
-  constexpr int NPAIRW = (sizeof(T) == 2) ? TC / 2 : 0;
+  constexpr int NPAIRW = (sizeof(T) <= 2) ? TC / 2 : 0;      // f16: 16-byte stores; fp8: 8-byte stores (instead of 4)
   const bool pair8 = NPAIRW > 0 && a.pair8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -740,6 +740,20 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
               blo[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s2[r] : fq == 2 ? s4[r] : s6[r]);
               bhi[r] = __int_as_float(fq == 0 ? s1[r] : fq == 1 ? s3[r] : fq == 2 ? s5[r] : s7[r]);
             }
+            float slo[4] = {1.f, 1.f, 1.f, 1.f}, shi[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (is_fp8<T>::value) {        // per-output-channel dequantisation scales, same scalar-load route
+              const float* qp = sgpr_ptr(a.qscale + (nt < a.cout ? nt : 0));
+              asm volatile("s_load_dwordx4 %0, %8, 0x0\n\ts_load_dwordx4 %1, %8, 0x10\n\ts_load_dwordx4 %2, %8, 0x20\n\t"
+                           "s_load_dwordx4 %3, %8, 0x30\n\ts_load_dwordx4 %4, %8, 0x40\n\ts_load_dwordx4 %5, %8, 0x50\n\t"
+                           "s_load_dwordx4 %6, %8, 0x60\n\ts_load_dwordx4 %7, %8, 0x70\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(s5), "=&s"(s6), "=&s"(s7) : "s"(qp));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                slo[r] = __int_as_float(fq == 0 ? s0[r] : fq == 1 ? s2[r] : fq == 2 ? s4[r] : s6[r]);
+                shi[r] = __int_as_float(fq == 0 ? s1[r] : fq == 1 ? s3[r] : fq == 2 ? s5[r] : s7[r]);
+              }
+            }
+            constexpr int ESP = (int)sizeof(T);
             v4ie_t rv[TPW];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) rv[j] = (v4ie_t){0, 0, 0, 0};
@@ -747,8 +761,9 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
 #pragma unroll
               for (int j = 0; j < TPW; ++j) {
                 const int m = m0 + (wp * TPW + j) * 16 + frow;
-                const uint32_t ro = (m < a.M && n < a.cout) ? (uint32_t)((m * a.res_ld + a.res_choff + n) * 2) : kOob;
-                rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+                const uint32_t ro = (m < a.M && n < a.cout) ? (uint32_t)((m * a.res_ld + a.res_choff + n) * ESP) : kOob;
+                if constexpr (ESP == 2) rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+                else { const v2i_t r2 = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0); rv[j] = (v4ie_t){r2[0], r2[1], 0, 0}; }
               }
             }
 #pragma unroll
@@ -757,18 +772,31 @@ __global__ __launch_bounds__(512) void conv_dmap_kernel(const ConvArgs a) {
               float v[8];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float x0 = acc[2 * p][j][r] + blo[r], x1 = acc[2 * p + 1][j][r] + bhi[r];
+                float x0 = is_fp8<T>::value ? fmaf(acc[2 * p][j][r], slo[r], blo[r]) : acc[2 * p][j][r] + blo[r];
+                float x1 = is_fp8<T>::value ? fmaf(acc[2 * p + 1][j][r], shi[r], bhi[r]) : acc[2 * p + 1][j][r] + bhi[r];
                 if (a.act) { x0 = silu_fast(x0); x1 = silu_fast(x1); }
                 v[r] = x0; v[4 + r] = x1;
               }
-              if (a.res) {
-                const f16x8 hr = *reinterpret_cast<const f16x8*>(&rv[j]);
+              const uint32_t so = (m < a.M && n < a.cout) ? (uint32_t)((m * a.dst_ld + a.dst_choff + n) * ESP) : kOob;
+              if constexpr (ESP == 2) {
+                if (a.res) {
+                  const f16x8 hr = *reinterpret_cast<const f16x8*>(&rv[j]);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
+                  for (int r = 0; r < 8; ++r) v[r] += (float)hr[r];
+                }
+                const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                if (!ABL(8)) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, MIYOLO_ST_AUX);
+              } else {
+                if (a.res) {
+                  float ra[4], rb[4];
+                  unpack_fp8x4((uint32_t)rv[j][0], ra); unpack_fp8x4((uint32_t)rv[j][1], rb);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) { v[r] = fmaf(ra[r], a.res_scale, v[r]); v[4 + r] = fmaf(rb[r], a.res_scale, v[4 + r]); }
+                }
+                const float q = a.out_inv_scale;
+                const v2i_t o = {(int)pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q), (int)pack_fp8x4(v[4] * q, v[5] * q, v[6] * q, v[7] * q)};
+                if (!ABL(8)) __builtin_amdgcn_raw_buffer_store_b64(o, rdst, so, 0, MIYOLO_ST_AUX);
               }
-              const f16x8 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-              const uint32_t so = (m < a.M && n < a.cout) ? (uint32_t)((m * a.dst_ld + a.dst_choff + n) * 2) : kOob;
-              if (!ABL(8)) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4ie_t*>(&hv), rdst, so, 0, MIYOLO_ST_AUX);
               acc[2 * p][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[2 * p + 1][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
           }
@@ -900,7 +928,7 @@ inline hipError_t launch_conv_dmap(const ConvArgs& a, hipStream_t s, int ncu, in
   ConvCfg c = pick_dmap_cfg(a.cout, a.M, ncu, a.ksize);
   if (force_wc > 0 && force_tc > 0) c = {force_wc, force_tc};
   ConvArgs b = a;
-  b.pair8 = (pair8 && sizeof(T) == 2 && !a.out_f32 && a.vec_ok && a.cout % 16 == 0 && a.dst_ld % 8 == 0 && a.dst_choff % 8 == 0 &&
+  b.pair8 = (pair8 && sizeof(T) <= 2 && !a.out_f32 && a.vec_ok && a.cout % 16 == 0 && a.dst_ld % 8 == 0 && a.dst_choff % 8 == 0 &&
              (!a.res || (a.res_ld % 8 == 0 && a.res_choff % 8 == 0))) ? 1 : 0;
   if (a.ksize == 3) return launch_dmap_ks<T, 3>(b, c, s, ncu);
   return launch_dmap_ks<T, 1>(b, c, s, ncu);
