@@ -326,7 +326,7 @@ def kernel_name(cfg, kind, dtype):
         return "conv_stem2<%s,tc%d>" % (dtype, cfg % 10)           # the stem and the stride-2 conv behind it in one launch
     if cfg >= 9000:
         return "conv_bneck<%s,tc%d>" % (dtype, cfg % 10)           # two 3x3 convs of a narrow Bottleneck in one launch
-    fam = ("conv_h3" if cfg >= 8000 and (cfg // 10) % 10 == 5 else "conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else
+    fam = ("conv_h4" if cfg >= 8000 and (cfg // 10) % 10 == 6 else "conv_h3" if cfg >= 8000 and (cfg // 10) % 10 == 5 else "conv_h2" if cfg >= 8000 else "conv_t2d" if cfg >= 7000 else "conv_dmh" if cfg >= 6000 else "conv_ws" if cfg >= 5000 else
            "conv_halop" if cfg >= 4000 else "conv_dmap" if cfg >= 3000 else "conv_halo" if cfg >= 2000 else "conv_dma" if cfg >= 1000 else "conv_igemm")
     return "%s<%s,k%d,wc%d,tc%d>" % (fam, dtype, (cfg // 100) % 10, (cfg // 10) % 10, cfg % 10)
 

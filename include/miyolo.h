@@ -209,7 +209,8 @@ int miyolo_classify_launches(miyolo_handle h, int H, int W, size_t* lds_bytes);
  * runs on conv_h3.h - the halo-slab kernel cut for three workgroups per CU, 128-pixel tiles, bit-identical results - where its
  * tile count fills the chip better than conv_h2's, i.e. on the 20 x 20 level; 1: wherever eligible; 0: never), "pair8" (1 default: the
  * ring kernel stores f16 outputs 16 bytes at a time over channel-tile pairs where the views are 8-channel aligned; 0: 8 bytes;
- * same results), "pw" (0 default;
+ * same results), "h4" (0 default; 1: 3x3 stride-1 F16 layers on 80- / 160-wide maps run on conv_h4.h - one workgroup per CU,
+ * 512-register waves; bit-identical, measured 38-45 % slower: an experiment), "pw" (0 default;
  * 1: in F16 an eligible 1x1 layer runs on the streaming kernel conv_pw.h - pixel fragments loaded straight into registers,
  * weights through the LDS by a producer wave; bit-identical results, measured 6-8 % slower than the ring kernel), "cls_mega" (1 default: an f16 classifier whose activations fit LDS runs as ONE launch, cls_mega.h; 0: one launch per
  * layer; bit-identical results), "head_lanes" (1 default: detect runs the Detect head's independent conv chains - per level

@@ -21,6 +21,7 @@
 #include "conv_h2.h"
 #include "conv_h3.h"
 #include "conv_pw.h"
+#include "conv_h4.h"
 // Earlier kernel generations / experiments (persistent halo, warp-specialised, two-workgroup, first halo prototype):
 // compiled only with `build.sh experiments` (-DMIYOLO_EXPERIMENTS=1); the shipped library carries conv_igemm.h
 // (conv_impl 0) and conv_dma.h (1) as the simple bit-exact cross-checks of the default kernels.
@@ -78,6 +79,8 @@ struct miyolo_engine {
   int h2_min_util = 70;     // ... = pixel utilisation of its 256-pixel tiles, in percent
   int pw = 0;               // 1: conv_impl 3, f16: eligible 1x1 layers on the streaming kernel (conv_pw.h) - round-3 experiment, 6-8 % slower than the ring kernel: off
   int pair8 = 1;            // conv_dmap.h: 16-byte f16 stores over channel-tile pairs (0: 8-byte stores; same results)
+  int h4 = 0;               // experiment (conv_h4.h): 3x3 stride-1 f16 layers whose map its 480/512-pixel tiles cover >= h4_min_util % on the one-workgroup-per-CU kernel
+  int h4_min_util = 85;
   int h3 = 2;               // conv_impl 3, f16: 3x3 stride-1 layers on the three-workgroups-per-CU form of the halo-slab kernel (conv_h3.h):
                             // 0 never, 1 wherever eligible, 2 (default) where its tile count fills the chip better (h3_preferred)
   int h3_min_util = 75;     // ... and its 128-pixel tiles cover at least this share of the map
@@ -443,6 +446,9 @@ int run_op(miyolo_engine* h, const miyolo_op& op, const Plan& p, const void* in,
       bool done_h3 = false;
       if constexpr (sizeof(T) == 2) {
         if (h->conv_impl == 9 && h3_eligible(a, 0.0)) { HIP_TRY(h, launch_conv_h3(a, s)); done_h3 = true; }
+        else if ((h->conv_impl == 10 && h4_eligible(a, 0.0)) || (h->conv_impl == 3 && h->h4 && h->force_wc == 0 && h4_eligible(a, 0.01 * h->h4_min_util))) {
+          HIP_TRY(h, launch_conv_h4(a, s)); done_h3 = true;
+        }
       }
       if (done_h3) {}
       else if (h->conv_impl == 8 && h2_eligible<T>(a, 0.0)) HIP_TRY(h, launch_conv_h2<T>(a, s, h->ncu, h->h2_warm));
@@ -560,6 +566,13 @@ int conv_cfg_id(const miyolo_engine* h, const miyolo_op& op, const Plan& p) {
                    t2d_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, h->desc.dtype == MIYOLO_F16 ? 2 : 4, h->desc.dtype == MIYOLO_F16 ? 8 : 4, &tg, &tlds);
   const bool s1 = op.ksize == 3 && op.stride == 1 && op.n_src == 1 && !op.src[0].upsample && ob.dtype != MIYOLO_F32 && op.cout % 8 == 0;
   const bool h2_first = h->desc.dtype == MIYOLO_F16 && op.res.buf < 0 && h->desc.task == 0;   // as run_op: narrow layers without a residual
+  if (s1 && (h->conv_impl == 10 || (h->conv_impl == 3 && h->h4 && h->force_wc == 0)) && h->desc.dtype == MIYOLO_F16) {
+    H2Geom g4; size_t l4; int geo4;
+    const int tc = h2_pick_tc(op.cout, 2);
+    if ((tc == 6 || tc == 4) && h4_shape(op.cin, op.cout, p.B, p.H / ob.down, p.W / ob.down, tc, &g4, &l4, &geo4) &&
+        (h->conv_impl == 10 || h4_util(g4, p.H / ob.down, p.W / ob.down) >= 0.01 * h->h4_min_util))
+      return 8000 + 300 + 60 + tc;                          // conv_h4_kernel<TC>
+  }
   if (s1 && h->conv_impl == 9 && h->desc.dtype == MIYOLO_F16) {
     H2Geom g3; size_t l3; int geo3;
     const int tc = h2_pick_tc(op.cout, 2);
@@ -1174,6 +1187,7 @@ int miyolo_create(const miyolo_desc* desc, const miyolo_buf* bufs, const miyolo_
   if (e == hipSuccess) e = set_h3_attrs();
   if (e == hipSuccess) e = set_bneck_attrs();
   if (e == hipSuccess) e = set_pw_attrs();
+  if (e == hipSuccess) e = set_h4_attrs();
   if (e == hipSuccess) e = set_stem2_attrs();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 1>();
   if (e == hipSuccess) e = set_dmap_attrs_ks<fp8_t, 3>();
@@ -1256,6 +1270,8 @@ int miyolo_set_option(miyolo_handle h, const char* key, int value) {
   if (!strcmp(key, "t2d")) { h->t2d = value; return 0; }
   if (!strcmp(key, "h2")) { h->h2 = value; return 0; }
   if (!strcmp(key, "pw")) { h->pw = value; return 0; }
+  if (!strcmp(key, "h4")) { h->h4 = value; return 0; }
+  if (!strcmp(key, "h4_min_util")) { h->h4_min_util = value; return 0; }
   if (!strcmp(key, "pair8")) { h->pair8 = value; return 0; }
   if (!strcmp(key, "h3")) { h->h3 = value; return 0; }
   if (!strcmp(key, "h3_min_util")) { h->h3_min_util = value; return 0; }

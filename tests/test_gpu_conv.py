@@ -435,3 +435,27 @@ def test_dmap_paired_stores_channel_slices():
         y = run_conv(dtype, [x], w, b, [(ld, off, cin, 0)], 1, 1, True, None, B, H, W, dst_ld=288, dst_off=dst_off, impl=3)
         assert rel_err(y[..., dst_off:dst_off + cout], ref) < TOL[dtype]
         assert np.all(y[..., :dst_off] == 7.0) and np.all(y[..., dst_off + cout:] == 7.0)
+
+
+# ---- conv_h4.h (conv_impl 10 / option h4): one workgroup per CU, 480 / 512-pixel tiles, 128-pixel wave tiles - round-3 experiment
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,W,B,res", [
+    (96, 96, 80, 80, 2, False),       # 40 x 12 tiles: 2 x 7 per image, last tile row partial (80 = 6 x 12 + 8)
+    (96, 96, 80, 80, 2, True),        # residual
+    (192, 192, 80, 80, 1, False),     # three chunks, two channel tiles
+    (192, 256, 40, 40, 2, False),     # 40-wide map, 256 = 2 x 96 + 64: channel tail tile
+    (64, 64, 32, 48, 3, True),        # 16 x 32 tiles, TC = 4, residual
+    (96, 72, 36, 20, 2, False),       # tiles wider than the map; channel tail (72 of 96)
+    (32, 96, 160, 160, 1, False),     # half chunk; 16 x 32 tiles on a 160-wide map
+])
+def test_h4_kernel_shapes_and_bit_identity_with_h2(cin, cout, H, W, B, res):
+    dtype = "f16"
+    rng = np.random.default_rng(cin * 11 + cout + H)
+    x = q(rng.standard_normal((B, H, W, cin)).astype(np.float32), dtype)
+    w = q((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32), dtype)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = q(rng.standard_normal((B, H, W, cout)).astype(np.float32), dtype) if res else None
+    y4 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=10)
+    y2 = run_conv(dtype, [x], w, b, [(cin, 0, cin, 0)], 3, 1, True, r, B, H, W, impl=8)
+    assert rel_err(y4, ref_conv(x, w, b, 1, True, r)) < TOL[dtype]
+    assert np.array_equal(y4, y2)
