@@ -71,6 +71,8 @@ def _run_conv_fp8(x_list, w, b, srcs, k, s, act, res, B, H, W, in_scales, out_sc
     (96, 96, 1, 1, 16, 16, 2, False),       # 1x1
     (576, 192, 1, 1, 8, 8, 2, False),
     (1152, 576, 1, 1, 8, 8, 1, False),
+    (96, 96, 1, 1, 16, 16, 2, True),        # ring kernel with a residual: the paired (8-byte) fp8 epilogue's residual path
+    (64, 128, 1, 1, 12, 12, 2, True),
 ])
 def test_fp8_conv_vs_dequantised_reference(cin, cout, k, s, H, W, B, res, impl):
     rng = np.random.default_rng(cin + cout * 3 + k)
